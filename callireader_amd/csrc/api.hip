@@ -1,0 +1,154 @@
+// C ABI of libcallireader_hip.so: lifetime, weights, single-operator entry points.
+// Stage orchestration lives in vision.hip / calli.hip / llm.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "attention.hpp"
+#include "ctx.hpp"
+#include "misc.hpp"
+#include "norm.hpp"
+
+static thread_local char g_err[512] = "";
+
+void cr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int cr_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const DevTensor* WT(cr_ctx* c, const std::string& name) {
+    auto it = c->w.find(name);
+    if (it == c->w.end()) { cr_set_error("weight '%s' was never loaded", name.c_str()); return nullptr; }
+    return &it->second;
+}
+const bf16* W(cr_ctx* c, const std::string& name) {
+    const DevTensor* t = WT(c, name);
+    return t ? (const bf16*)t->ptr : nullptr;
+}
+
+int ws_ensure(cr_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return CR_OK;
+    // growth happens only the first time a shape is seen; never inside a timed steady state
+    CR_HIP(hipDeviceSynchronize());
+    if (c->ws) CR_HIP(hipFree(c->ws));
+    c->ws = nullptr; c->ws_bytes = 0;
+    size_t want = bytes + (bytes >> 3);
+    if (hipMalloc((void**)&c->ws, want) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "workspace of %zu bytes", want);
+    c->ws_bytes = want;
+    return CR_OK;
+}
+
+static size_t dtype_size(int dt) { return dt == CR_BF16 ? 2 : dt == CR_F32 ? 4 : dt == CR_I64 ? 8 : dt == CR_I32 ? 4 : 0; }
+
+extern "C" {
+
+const char* cr_last_error(void) { return g_err; }
+int cr_abi_version(void) { return CR_ABI_VERSION; }
+
+int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
+    if (!desc || !out) return cr_fail(CR_ERR_ARG, "cr_create: null argument");
+    CR_HIP(hipSetDevice(device));
+    cr_ctx* c = new cr_ctx();
+    c->device = device;
+    c->d = *desc;
+    c->scratch_bytes = 1 << 20;
+    if (hipMalloc((void**)&c->scratch, c->scratch_bytes) != hipSuccess) { delete c; return cr_fail(CR_ERR_NOMEM, "scratch"); }
+    hipMemset(c->scratch, 0, c->scratch_bytes);
+    *out = c;
+    return CR_OK;
+}
+
+int cr_destroy(cr_ctx* c) {
+    if (!c) return CR_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& kv : c->w) if (kv.second.ptr) hipFree(kv.second.ptr);
+    if (c->ws) hipFree(c->ws);
+    if (c->scratch) hipFree(c->scratch);
+    delete c;
+    return CR_OK;
+}
+
+int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, const int64_t* shape, int ndim,
+                   int src_is_host, void* stream) {
+    if (!c || !name || !src || !shape || ndim <= 0 || ndim > 8) return cr_fail(CR_ERR_ARG, "cr_load_weight: bad argument");
+    const size_t es = dtype_size(dtype);
+    if (!es) return cr_fail(CR_ERR_ARG, "cr_load_weight(%s): unknown dtype %d", name, dtype);
+    DevTensor t;
+    t.dtype = dtype;
+    t.shape.assign(shape, shape + ndim);
+    if (t.numel() <= 0) return cr_fail(CR_ERR_ARG, "cr_load_weight(%s): empty tensor", name);
+    t.bytes = (size_t)t.numel() * es;
+    auto it = c->w.find(name);
+    if (it != c->w.end()) {
+        if (it->second.bytes != t.bytes) { hipFree(it->second.ptr); c->w.erase(it); it = c->w.end(); }
+        else t.ptr = it->second.ptr;
+    }
+    if (!t.ptr && hipMalloc(&t.ptr, (t.bytes + 255) & ~(size_t)255) != hipSuccess)
+        return cr_fail(CR_ERR_NOMEM, "cr_load_weight(%s): %zu bytes", name, t.bytes);
+    CR_HIP(hipMemcpyAsync(t.ptr, src, t.bytes, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (src_is_host) CR_HIP(hipStreamSynchronize((hipStream_t)stream));   // caller may free host memory right away
+    c->w[name] = t;
+    c->finalized = false;
+    return CR_OK;
+}
+
+// ---- single operators ---------------------------------------------------------------------------
+int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc,
+               const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
+               void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)Wt; p.ldw = ldw; p.C = C; p.ldc = ldc;
+    p.bias = (const bf16*)bias; p.scale = (const bf16*)scale; p.res = (const bf16*)res; p.ldr = ldr;
+    p.M = M; p.N = N; p.K = K; p.group = group;
+    int r = launch_gemm(epi, p, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_gemm(epi=%d, M=%d, N=%d, K=%d) rejected or failed to launch", epi, M, N, K);
+    return CR_OK;
+}
+
+int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* beta, int64_t rows, int n, float eps,
+                    int pixel_shuffle, void* stream) {
+    NormParams p{};
+    p.in = (const bf16*)in; p.ld_in = n; p.out = (bf16*)out; p.ld_out = n;
+    p.gamma = (const bf16*)gamma; p.beta = (const bf16*)beta; p.rows = rows; p.eps = eps;
+    int r = launch_layernorm(p, n, pixel_shuffle ? 1 : 0, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_layernorm(rows=%lld, n=%d) rejected or failed", (long long)rows, n);
+    return CR_OK;
+}
+
+int cr_op_rmsnorm(const void* in, void* out, const void* gamma, int64_t rows, int n, float eps, void* stream) {
+    NormParams p{};
+    p.in = (const bf16*)in; p.ld_in = n; p.out = (bf16*)out; p.ld_out = n;
+    p.gamma = (const bf16*)gamma; p.rows = rows; p.eps = eps;
+    int r = launch_rmsnorm(p, n, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_rmsnorm(rows=%lld, n=%d) rejected or failed", (long long)rows, n);
+    return CR_OK;
+}
+
+int cr_op_attention(const void* q, const void* k, const void* v, void* o, const int64_t* s, int B, int H,
+                    int Sq, int Sk, int head_dim, int kv_group, int causal, int q_pos0, float q_prescale, float s_div,
+                    void* stream) {
+    if (!s) return cr_fail(CR_ERR_ARG, "cr_op_attention: strides");
+    AttnParams p{};
+    p.Q = (const bf16*)q; p.K = (const bf16*)k; p.V = (const bf16*)v; p.O = (bf16*)o;
+    p.q_bs = s[0]; p.q_rs = s[1]; p.q_hs = s[2];
+    p.k_bs = s[3]; p.k_rs = s[4]; p.k_hs = s[5];
+    p.v_bs = s[6]; p.v_rs = s[7]; p.v_hs = s[8];
+    p.o_bs = s[9]; p.o_rs = s[10]; p.o_hs = s[11];
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.kv_group = kv_group; p.q_pos0 = q_pos0;
+    p.q_prescale = q_prescale; p.s_div = s_div;
+    int r = launch_flash_attn(p, head_dim, causal != 0, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_attention(d=%d) rejected or failed", head_dim);
+    return CR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+// Fused softmax attention for gfx950 (ViT non-causal S=1025 d=64; InternLM2 causal GQA d=128).
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+// K/V tiles of 64 keys arrive by LDS-DMA (global_load_lds_dwordx4) into two LDS buffers.
+//   S^T = K . Q^T        v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR-swizzled
+//                        chunks), B = Q fragment held in registers for the whole kernel.
+//                        Swapped operands put the QUERY on the lane and the 32 keys of a block in
+//                        16 registers x 2 half-waves: row max / row sum are register-local plus one
+//                        cross-half shuffle, and the O rescale factor is one scalar per lane.
+//   O^T += V^T . P^T     the S^T accumulators, packed to bf16, ARE the B operand (k order permuted
+//                        as the MFMA C layout dictates); V^T comes from the row-major V tile through
+//                        ds_read_b64_tr_b16 with the same k permutation, so V is never transposed in
+//                        memory.
+// Rounding points follow the eager reference:
+//   ViT  (modeling_intern_vit.py:225-229): q*scale in bf16 (exact, 2^-3), scores rounded to bf16,
+//        softmax in fp32 over them;
+//   LLM  (modeling_internlm2.py:393-410): scores rounded to bf16, divided by sqrt(d) -> bf16,
+//        causal mask, fp32 softmax, probabilities cast to bf16 before .V (we cast the
+//        un-normalised exp and divide the fp32 accumulator by the fp32 row sum at the end).
+#include "attention.hpp"
+
+namespace {
+
+template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
+template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = D * 2;
+    constexpr int TILE = 64 * ROWB;
+    constexpr int CPR = D / 8;
+    constexpr int RPI = 1024 / ROWB;
+    constexpr int IPW = 64 / RPI / 4;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    const int kvh = head / p.kv_group;
+    const int qi = qb * 128 + wave * 32 + l31;
+    const int qi_c = min(qi, p.Sq - 1);
+
+    // ---- Q fragment (B operand of K.Q^T): lane (query l31, half hh) holds Q[q][16ks + 8hh .. +7]
+    bf16x8 qf[KS];
+    {
+        const bf16* qp = p.Q + (int64_t)batch * p.q_bs + (int64_t)qi_c * p.q_rs + (int64_t)head * p.q_hs + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            qf[ks] = *(const bf16x8*)(qp + ks * 16);
+            if (p.q_prescale != 1.0f) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) qf[ks][e] = f2bf(bf2f(qf[ks][e]) * p.q_prescale);
+            }
+        }
+    }
+
+    const bf16* Kb = p.K + (int64_t)batch * p.k_bs + (int64_t)kvh * p.k_hs;
+    const bf16* Vb = p.V + (int64_t)batch * p.v_bs + (int64_t)kvh * p.v_hs;
+
+    auto stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int ii = 0; ii < IPW; ii++) {
+            const int r = (wave * IPW + ii) * RPI + lane / CPR;
+            const int cp = lane % CPR;
+            const int key = min(kt * 64 + r, p.Sk - 1);
+            const bf16* ks = Kb + (int64_t)key * p.k_rs + ((cp ^ kswz<D>(r)) * 8);
+            const bf16* vs = Vb + (int64_t)key * p.v_rs + ((cp ^ vswz<D>(r)) * 8);
+            char* dst = smem + buf * (2 * TILE) + (wave * IPW + ii) * 1024;
+            __builtin_amdgcn_global_load_lds(CR_GLB(ks), CR_LDS(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CR_GLB(vs), CR_LDS(dst + TILE), 16, 0, 0);
+        }
+    };
+
+    int nt = (p.Sk + 63) / 64;
+    if (CAUSAL) {
+        const int kmax = p.q_pos0 + min(qb * 128 + 127, p.Sq - 1);
+        nt = min(nt, kmax / 64 + 1);
+    }
+    const int qpos = p.q_pos0 + qi_c;
+
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) oacc[db][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // lane-constant pieces of the LDS addresses
+    const int k_lane_off = l31 * ROWB;
+    const int k_sw = kswz<D>(l31);
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int v_lane_row = 4 * hh + tq;
+    const int v_sw = vswz<D>(v_lane_row);
+    const int v_clow = (g & 1) * 2 + (tp >> 1);
+    const int v_lane_off = v_lane_row * ROWB + (tp & 1) * 8;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nt; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        const char* kbuf = smem + cur * (2 * TILE);
+        const char* vbuf = kbuf + TILE;
+
+        // ---- S^T = K . Q^T for two 32-key blocks ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) sacc[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const bf16x8 kf = *(const bf16x8*)(kbuf + kb * 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---- scores: reference rounding, masking, online softmax (query = lane) ----
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float s = rbf(sacc[kb][e]);
+                if (p.s_div != 1.0f) s = rbf(s / p.s_div);
+                const int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const bool ok = key < p.Sk && (!CAUSAL || key <= qpos);
+                s = ok ? s : -INFINITY;
+                sacc[kb][e] = s;
+                mloc = fmaxf(mloc, s);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float pe = __expf(sacc[kb][e] - m_new);
+                sacc[kb][e] = pe;
+                psum += pe;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; e++) pf[e] = f2bf(sacc[kb][8 * s + e]);
+#pragma unroll
+                for (int db = 0; db < DB; db++) {
+                    const int chunk = ((db * 4) ^ v_sw) | v_clow;
+                    const char* vp = vbuf + (kb * 32 + 16 * s) * ROWB + v_lane_off + chunk * 16;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp + 8 * ROWB));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (query, half) owns d = 32db + 8g4 + 4hh + 0..3 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qi < p.Sq) {
+        bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qi * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = f2bf(oacc[db][4 * g4 + e] * inv);
+                *(bf16x4*)(op + 32 * db + 8 * g4) = o;
+            }
+    }
+}
+
+template <int D, bool CAUSAL>
+int launch_t(const AttnParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 2 * 64 * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel<D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return CR_ERR_HIP;
+        attr_set = true;
+    }
+    dim3 grid((p.Sq + 127) / 128, p.H, p.B);
+    hipLaunchKernelGGL((flash_attn_kernel<D, CAUSAL>), grid, dim3(256), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+}  // namespace
+
+int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream) {
+    if (p.Sq <= 0 || p.Sk <= 0 || p.H <= 0 || p.B <= 0 || p.kv_group <= 0) return CR_ERR_ARG;
+    if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7) || (p.o_rs & 3)) return CR_ERR_ARG;
+    if (head_dim == 64) return causal ? launch_t<64, true>(p, stream) : launch_t<64, false>(p, stream);
+    if (head_dim == 128) return causal ? launch_t<128, true>(p, stream) : launch_t<128, false>(p, stream);
+    return CR_ERR_ARG;
+}

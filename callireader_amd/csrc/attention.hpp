@@ -1,0 +1,18 @@
+#pragma once
+#include "common.hpp"
+
+// Strides are in elements.  Q/K/V/O are addressed as base + b*bs + row*rs + head*hs + d.
+struct AttnParams {
+    const bf16* Q; const bf16* K; const bf16* V; bf16* O;
+    int64_t q_bs, q_rs, q_hs;
+    int64_t k_bs, k_rs, k_hs;
+    int64_t v_bs, v_rs, v_hs;
+    int64_t o_bs, o_rs, o_hs;
+    int B, H, Sq, Sk;
+    int kv_group;        // query heads per kv head (GQA): kv head = head / kv_group
+    int q_pos0;          // causal: absolute position of query row 0 (keys start at position 0)
+    float q_prescale;    // multiply q in bf16 before Q.K^T (ViT: 64^-0.5, exact); 1 = off
+    float s_div;         // divide bf16-rounded scores (LLM: sqrt(128)); 1 = off
+};
+
+int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream);

@@ -1,0 +1,60 @@
+// Shared device/host helpers for the CalliReader gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define CR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#include "../../include/callireader_hip.h"   // error codes of the C ABI
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }      // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }  // round-trip through bf16
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- GEMM -----------------------------------------------------------------
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T); A and W row-major with K contiguous
+// (exactly how nn.Linear stores its weight), K % 64 == 0.
+enum GemmEpi {
+    EPI_STORE = 0,    // bf16(acc + bias)
+    EPI_GELU = 1,     // bf16(gelu(bf16(acc + bias)))
+    EPI_LS_RES = 2,   // bf16(res + bf16(bf16(acc + bias) * scale))         (ViT LayerScale + residual)
+    EPI_RES = 3,      // bf16(res + bf16(acc + bias))                       (LLM / resampler residual)
+    EPI_SWIGLU = 4,   // bf16(bf16(silu(bf16(g))) * bf16(u)), W rows interleaved [8 gate | 8 up]
+    EPI_PATCH = 5,    // patch-embed: bf16(bf16(acc + bias) + pos[1 + m % G]) -> row (m / G) * (G + 1) + 1 + m % G
+    EPI_F32 = 6,      // float(bf16(acc + bias))                            (logits: bf16 GEMM then .float())
+};
+
+struct GemmParams {
+    const bf16* A; int64_t lda;
+    const bf16* W; int64_t ldw;
+    void* C; int64_t ldc;
+    const bf16* bias;          // [N] or nullptr
+    const bf16* scale;         // [N] (EPI_LS_RES)
+    const bf16* res; int64_t ldr;   // residual rows (EPI_LS_RES / EPI_RES) or pos-emb (EPI_PATCH)
+    int M, N, K;
+    int group;                 // EPI_PATCH: patches per tile (1024)
+};
+
+int launch_gemm(int epi, const GemmParams& p, hipStream_t stream);

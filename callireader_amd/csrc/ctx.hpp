@@ -1,0 +1,60 @@
+// Context of libcallireader_hip.so: weights (library-owned device copies), derived
+// tensors, a grow-only device workspace.  Host-side C++ only; no torch types.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/callireader_hip.h"
+#include "common.hpp"
+
+struct DevTensor {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int dtype = CR_BF16;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct cr_ctx {
+    int device = 0;
+    cr_model_desc d{};
+    bool finalized = false;
+    std::unordered_map<std::string, DevTensor> w;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // small persistent device scratch (counters, argmax partials)
+    char* scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+void cr_set_error(const char* fmt, ...);
+int cr_fail(int code, const char* fmt, ...);
+#define CR_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return cr_fail(CR_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#define CR_TRY(call)                       \
+    do {                                   \
+        int r_ = (call);                   \
+        if (r_ != CR_OK) return r_;        \
+    } while (0)
+
+// weight lookup helpers (api.hip)
+const bf16* W(cr_ctx* c, const std::string& name);
+const DevTensor* WT(cr_ctx* c, const std::string& name);
+int ws_ensure(cr_ctx* c, size_t bytes);
+
+// simple bump allocator over the workspace
+struct Arena {
+    char* base; size_t off = 0;
+    explicit Arena(char* b) : base(b) {}
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = (T*)(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};

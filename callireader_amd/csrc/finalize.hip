@@ -1,0 +1,18 @@
+// cr_finalize: derive re-laid-out tensors once the checkpoint tensors are in.
+#include "ctx.hpp"
+
+int vit_finalize(cr_ctx* c, hipStream_t st);
+int calli_finalize(cr_ctx* c, hipStream_t st);
+int llm_finalize(cr_ctx* c, hipStream_t st);
+
+extern "C" int cr_finalize(cr_ctx* c, void* stream) {
+    if (!c) return cr_fail(CR_ERR_ARG, "cr_finalize: null context");
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (c->w.count("vision_model.embeddings.patch_embedding.weight")) CR_TRY(vit_finalize(c, st));
+    if (c->w.count("normed_emb.weight")) CR_TRY(calli_finalize(c, st));
+    if (c->w.count("language_model.model.layers.0.feed_forward.w1.weight")) CR_TRY(llm_finalize(c, st));
+    CR_HIP(hipStreamSynchronize(st));
+    c->finalized = true;
+    return CR_OK;
+}

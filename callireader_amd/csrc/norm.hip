@@ -1,0 +1,121 @@
+// LayerNorm / RMSNorm rows for gfx950.  HBM-bound: each thread owns 16 contiguous
+// bf16 (two 16-B loads), statistics in fp32 with wave shuffles (+ LDS across
+// the 4 waves when a row spans the workgroup), one 16-B store pair per thread.
+//
+// Reference semantics:
+//   nn.LayerNorm(bf16): fp32 mean/var over the row, y = (x-mean)*rstd*gamma+beta rounded once
+//     (modeling_intern_vit.py:280-281 eps 1e-6; mlp1[0] modeling_internvl_chat.py:186 eps 1e-5;
+//      perceiver_resampler.py:21-22,79,134 eps 1e-5)
+//   InternLM2RMSNorm (modeling_internlm2.py:138-143): fp32 x*rsqrt(mean(x^2)+eps) -> bf16 -> * weight
+#include "norm.hpp"
+
+namespace {
+
+__device__ __forceinline__ void load16(const bf16* p, float* x) {
+    bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { x[e] = bf2f(a[e]); x[8 + e] = bf2f(b[e]); }
+}
+__device__ __forceinline__ void store16(bf16* p, const float* y) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { a[e] = f2bf(y[e]); b[e] = f2bf(y[8 + e]); }
+    *(bf16x8*)p = a; *(bf16x8*)(p + 8) = b;
+}
+
+// TPR threads per row (N = 16 * TPR); 256-thread workgroup holds 256/TPR rows.
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if (TPR == 64) return v;
+    // TPR == 256: combine the 4 waves
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int TPR, int MODE>   // MODE 0: plain rows, 1: pixel-shuffle gather (N = 4096 from [T,1025,1024])
+__global__ __launch_bounds__(256) void layernorm_kernel(const NormParams p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    constexpr int RPB = 256 / TPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + tid / TPR;
+    const int t = tid % TPR;
+    const bool live = row < p.rows;
+    const int64_t r = live ? row : p.rows - 1;
+    const bf16* src;
+    if (MODE == 1) {
+        // out row r = tile*256 + a*16 + b ; features [q*1024 + c], q = t/64:
+        //   source token 1 + (2a + (q>>1))*32 + (2b + (q&1))   (modeling_internvl_chat.py:283-297, 311-316)
+        const int tile = (int)(r >> 8), ab = (int)(r & 255), a = ab >> 4, b = ab & 15, q = t >> 6;
+        const int tok = 1 + (2 * a + (q >> 1)) * 32 + (2 * b + (q & 1));
+        src = p.in + ((int64_t)tile * 1025 + tok) * 1024 + (t & 63) * 16;
+    } else {
+        src = p.in + r * p.ld_in + t * 16;
+    }
+    float x[16];
+    load16(src, x);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s += x[e];
+    const float inv_n = 1.0f / (16 * TPR);
+    const float mean = row_sum<TPR>(s, red, tid) * inv_n;
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { const float d = x[e] - mean; v += d * d; }
+    const float var = row_sum<TPR>(v, red, tid) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    float g[16], bb[16], y[16];
+    load16(p.gamma + t * 16, g);
+    load16(p.beta + t * 16, bb);
+#pragma unroll
+    for (int e = 0; e < 16; e++) y[e] = (x[e] - mean) * rstd * g[e] + bb[e];
+    if (live) {
+        int64_t orow = row;
+        if (p.out_group > 0) orow = (row / p.in_group) * p.out_group + p.out_off + row % p.in_group;
+        store16(p.out + orow * p.ld_out + t * 16, y);
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm4096_kernel(const NormParams p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    float x[16];
+    load16(p.in + row * p.ld_in + tid * 16, x);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s += x[e] * x[e];
+    const float var = row_sum<256>(s, red, tid) * (1.0f / 4096.0f);
+    const float rs = rsqrtf(var + p.eps);
+    float g[16], y[16];
+    load16(p.gamma + tid * 16, g);
+#pragma unroll
+    for (int e = 0; e < 16; e++) y[e] = g[e] * rbf(x[e] * rs);
+    store16(p.out + row * p.ld_out + tid * 16, y);
+}
+
+}  // namespace
+
+int launch_layernorm(const NormParams& p, int n, int mode, hipStream_t stream) {
+    if (p.rows <= 0) return CR_OK;
+    if (mode == 1) {
+        if (n != 4096) return CR_ERR_ARG;
+        hipLaunchKernelGGL((layernorm_kernel<256, 1>), dim3((unsigned)p.rows), dim3(256), 0, stream, p);
+    } else if (n == 1024) {
+        hipLaunchKernelGGL((layernorm_kernel<64, 0>), dim3((unsigned)((p.rows + 3) / 4)), dim3(256), 0, stream, p);
+    } else if (n == 4096) {
+        hipLaunchKernelGGL((layernorm_kernel<256, 0>), dim3((unsigned)p.rows), dim3(256), 0, stream, p);
+    } else {
+        return CR_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+int launch_rmsnorm(const NormParams& p, int n, hipStream_t stream) {
+    if (p.rows <= 0) return CR_OK;
+    if (n != 4096) return CR_ERR_ARG;
+    hipLaunchKernelGGL(rmsnorm4096_kernel, dim3((unsigned)p.rows), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}

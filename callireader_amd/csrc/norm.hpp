@@ -1,0 +1,17 @@
+#pragma once
+#include "common.hpp"
+
+struct NormParams {
+    const bf16* in; int64_t ld_in;
+    bf16* out; int64_t ld_out;
+    const bf16* gamma;
+    const bf16* beta;          // nullptr for RMSNorm
+    int64_t rows;
+    float eps;
+    // optional output row regrouping: out_row = (row / in_group) * out_group + out_off + row % in_group
+    int in_group, out_group, out_off;
+};
+
+// mode 0: rows of n (1024 | 4096) bf16; mode 1: pixel-shuffle gather feeding mlp1's LayerNorm (n = 4096)
+int launch_layernorm(const NormParams& p, int n, int mode, hipStream_t stream);
+int launch_rmsnorm(const NormParams& p, int n, hipStream_t stream);

@@ -1,0 +1,162 @@
+// Vision stage: InternViT-300M encoder + pixel-shuffle/mlp1 projector.
+//   reference: InternVL/modeling_intern_vit.py:138-437, InternVL/modeling_internvl_chat.py:283-319
+//
+// Per tile chunk (<= VIT_CHUNK tiles, M = tiles * 1025 rows) and per layer, 7 launches:
+//   LN1 -> GEMM qkv(+bias) -> flash attention -> GEMM proj(+bias, *ls1, +x, in place)
+//   LN2 -> GEMM fc1(+bias, GELU) -> GEMM fc2(+bias, *ls2, +x, in place)
+// The residual stream x lives in the caller's output buffer; nothing is copied.
+#include "attention.hpp"
+#include "ctx.hpp"
+#include "misc.hpp"
+#include "norm.hpp"
+
+static constexpr int VIT_CHUNK = 64;
+static constexpr int C1 = 1024, C3 = 3072, FF = 4096, TOK = 1025, KPAD = 640;
+
+int vit_finalize(cr_ctx* c, hipStream_t st) {
+    const DevTensor* pw = WT(c, "vision_model.embeddings.patch_embedding.weight");
+    if (!pw) return CR_ERR_STATE;
+    if (pw->numel() != (int64_t)C1 * 588) return cr_fail(CR_ERR_ARG, "patch_embedding.weight must be [1024,3,14,14]");
+    DevTensor t;
+    t.dtype = CR_BF16; t.shape = {C1, KPAD}; t.bytes = (size_t)C1 * KPAD * 2;
+    auto it = c->w.find("derived.patch_w");
+    if (it != c->w.end()) t.ptr = it->second.ptr;
+    else CR_HIP(hipMalloc(&t.ptr, t.bytes));
+    CR_HIP(hipMemsetAsync(t.ptr, 0, t.bytes, st));
+    CR_HIP(hipMemcpy2DAsync(t.ptr, KPAD * 2, pw->ptr, 588 * 2, 588 * 2, C1, hipMemcpyDeviceToDevice, st));
+    c->w["derived.patch_w"] = t;
+    return CR_OK;
+}
+
+static int gemm(int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
+                const bf16* scale, const bf16* res, int64_t ldr, int M, int N, int K, int group, hipStream_t st) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.scale = scale; p.res = res; p.ldr = ldr;
+    p.M = M; p.N = N; p.K = K; p.group = group;
+    int r = launch_gemm(epi, p, st);
+    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) failed", epi, M, N, K);
+    return CR_OK;
+}
+
+static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) {
+    const int M = T * TOK;
+    Arena ar(c->ws);
+    bf16* col = ar.take<bf16>((size_t)T * 1024 * KPAD);
+    bf16* h = ar.take<bf16>((size_t)M * C1);       // LN output, later attention output
+    bf16* qkv = ar.take<bf16>((size_t)M * C3);
+    bf16* f = ar.take<bf16>((size_t)M * FF);
+
+    const bf16* patch_w = W(c, "derived.patch_w");
+    const bf16* patch_b = W(c, "vision_model.embeddings.patch_embedding.bias");
+    const bf16* cls = W(c, "vision_model.embeddings.class_embedding");
+    const bf16* pos = W(c, "vision_model.embeddings.position_embedding");
+    if (!patch_w || !patch_b || !cls || !pos) return CR_ERR_STATE;
+
+    // embeddings (modeling_intern_vit.py:167-179); bicubic pos-emb resize is the identity at 448x448
+    CR_TRY(launch_im2col14(px, col, T, st));
+    CR_TRY(gemm(EPI_PATCH, col, KPAD, patch_w, KPAD, x, C1, patch_b, nullptr, pos, C1, T * 1024, C1, KPAD, 1024, st));
+    CR_TRY(launch_cls_rows(cls, pos, x, T, C1, TOK, st));
+
+    for (int l = 0; l < c->d.vit_layers; l++) {
+        const std::string p = "vision_model.encoder.layers." + std::to_string(l) + ".";
+        const bf16 *n1w = W(c, p + "norm1.weight"), *n1b = W(c, p + "norm1.bias");
+        const bf16 *n2w = W(c, p + "norm2.weight"), *n2b = W(c, p + "norm2.bias");
+        const bf16 *qkvw = W(c, p + "attn.qkv.weight"), *qkvb = W(c, p + "attn.qkv.bias");
+        const bf16 *pw = W(c, p + "attn.proj.weight"), *pb = W(c, p + "attn.proj.bias");
+        const bf16 *f1w = W(c, p + "mlp.fc1.weight"), *f1b = W(c, p + "mlp.fc1.bias");
+        const bf16 *f2w = W(c, p + "mlp.fc2.weight"), *f2b = W(c, p + "mlp.fc2.bias");
+        const bf16 *ls1 = W(c, p + "ls1"), *ls2 = W(c, p + "ls2");
+        if (!n1w || !n1b || !n2w || !n2b || !qkvw || !qkvb || !pw || !pb || !f1w || !f1b || !f2w || !f2b || !ls1 || !ls2)
+            return CR_ERR_STATE;
+
+        NormParams np{};
+        np.in = x; np.ld_in = C1; np.out = h; np.ld_out = C1; np.rows = M; np.eps = c->d.vit_ln_eps;
+        np.gamma = n1w; np.beta = n1b;
+        CR_TRY(launch_layernorm(np, C1, 0, st));
+        CR_TRY(gemm(EPI_STORE, h, C1, qkvw, C1, qkv, C3, qkvb, nullptr, nullptr, 0, M, C3, C1, 0, st));
+
+        AttnParams ap{};
+        ap.Q = qkv; ap.K = qkv + C1; ap.V = qkv + 2 * C1; ap.O = h;
+        ap.q_bs = ap.k_bs = ap.v_bs = (int64_t)TOK * C3; ap.q_rs = ap.k_rs = ap.v_rs = C3; ap.q_hs = ap.k_hs = ap.v_hs = 64;
+        ap.o_bs = (int64_t)TOK * C1; ap.o_rs = C1; ap.o_hs = 64;
+        ap.B = T; ap.H = 16; ap.Sq = TOK; ap.Sk = TOK; ap.kv_group = 1; ap.q_pos0 = 0;
+        ap.q_prescale = 0.125f; ap.s_div = 1.0f;
+        if (launch_flash_attn(ap, 64, false, st) != CR_OK) return cr_fail(CR_ERR_HIP, "vit attention launch failed");
+        CR_TRY(gemm(EPI_LS_RES, h, C1, pw, C1, x, C1, pb, ls1, x, C1, M, C1, C1, 0, st));
+
+        np.gamma = n2w; np.beta = n2b;
+        CR_TRY(launch_layernorm(np, C1, 0, st));
+        CR_TRY(gemm(EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
+        CR_TRY(gemm(EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
+    }
+    return CR_OK;
+}
+
+static size_t vit_ws_bytes(int T) {
+    const size_t M = (size_t)T * TOK;
+    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + 4096;
+}
+
+static int project_chunk(cr_ctx* c, const bf16* vit_out, int T, bf16* out, hipStream_t st) {
+    const int M = T * 256;
+    Arena ar(c->ws);
+    bf16* a = ar.take<bf16>((size_t)M * 4096);
+    bf16* b = ar.take<bf16>((size_t)M * 4096);
+    const bf16 *lw = W(c, "mlp1.0.weight"), *lb = W(c, "mlp1.0.bias");
+    const bf16 *w1 = W(c, "mlp1.1.weight"), *b1 = W(c, "mlp1.1.bias");
+    const bf16 *w3 = W(c, "mlp1.3.weight"), *b3 = W(c, "mlp1.3.bias");
+    if (!lw || !lb || !w1 || !b1 || !w3 || !b3) return CR_ERR_STATE;
+    NormParams np{};
+    np.in = vit_out; np.out = a; np.ld_out = 4096; np.rows = M; np.eps = 1e-5f; np.gamma = lw; np.beta = lb;
+    CR_TRY(launch_layernorm(np, 4096, 1, st));     // drop CLS + pixel_shuffle folded into the load
+    CR_TRY(gemm(EPI_GELU, a, 4096, w1, 4096, b, 4096, b1, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
+    CR_TRY(gemm(EPI_STORE, b, 4096, w3, 4096, out, 4096, b3, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
+    return CR_OK;
+}
+
+extern "C" {
+
+int cr_vit_forward(cr_ctx* c, const void* pixels, int T, void* out, void* stream) {
+    if (!c || !pixels || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_vit_forward: bad argument");
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_vit_forward: call cr_finalize after loading weights");
+    CR_HIP(hipSetDevice(c->device));
+    CR_TRY(ws_ensure(c, vit_ws_bytes(T < VIT_CHUNK ? T : VIT_CHUNK)));
+    for (int t0 = 0; t0 < T; t0 += VIT_CHUNK) {
+        const int tc = (T - t0) < VIT_CHUNK ? (T - t0) : VIT_CHUNK;
+        CR_TRY(vit_chunk(c, (const bf16*)pixels + (size_t)t0 * 3 * 448 * 448, tc, (bf16*)out + (size_t)t0 * TOK * C1,
+                         (hipStream_t)stream));
+    }
+    return CR_OK;
+}
+
+int cr_project(cr_ctx* c, const void* vit_out, int T, void* out, void* stream) {
+    if (!c || !vit_out || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_project: bad argument");
+    CR_HIP(hipSetDevice(c->device));
+    const int CH = 256;
+    CR_TRY(ws_ensure(c, (size_t)(T < CH ? T : CH) * 256 * 4096 * 2 * 2 + 4096));
+    for (int t0 = 0; t0 < T; t0 += CH) {
+        const int tc = (T - t0) < CH ? (T - t0) : CH;
+        CR_TRY(project_chunk(c, (const bf16*)vit_out + (size_t)t0 * TOK * C1, tc, (bf16*)out + (size_t)t0 * 256 * 4096,
+                             (hipStream_t)stream));
+    }
+    return CR_OK;
+}
+
+int cr_extract_feature(cr_ctx* c, const void* pixels, int T, void* out, void* stream) {
+    if (!c || !pixels || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_extract_feature: bad argument");
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_extract_feature: call cr_finalize after loading weights");
+    CR_HIP(hipSetDevice(c->device));
+    // ViT output of a chunk sits at the top of the workspace, below it the per-chunk scratch of both stages.
+    for (int t0 = 0; t0 < T; t0 += VIT_CHUNK) {
+        const int tc = (T - t0) < VIT_CHUNK ? (T - t0) : VIT_CHUNK;
+        const size_t inner = vit_ws_bytes(tc) > (size_t)tc * 256 * 4096 * 4 + 4096 ? vit_ws_bytes(tc) : (size_t)tc * 256 * 4096 * 4 + 4096;
+        const size_t xbytes = (size_t)tc * TOK * C1 * 2;
+        CR_TRY(ws_ensure(c, inner + 256 + xbytes));
+        bf16* x = (bf16*)(c->ws + ((inner + 255) & ~(size_t)255));
+        CR_TRY(vit_chunk(c, (const bf16*)pixels + (size_t)t0 * 3 * 448 * 448, tc, x, (hipStream_t)stream));
+        CR_TRY(project_chunk(c, x, tc, (bf16*)out + (size_t)t0 * 256 * 4096, (hipStream_t)stream));
+    }
+    return CR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+"""Thin torch<->C-ABI plumbing: device buffers and streams come from PyTorch-ROCm,
+all compute goes through libcallireader_hip.so.  No torch math on the hot path."""
+import ctypes as C
+
+import torch
+
+from . import _binding as B
+from .config import ModelDims
+
+_DT = {torch.bfloat16: B.CR_BF16, torch.float32: B.CR_F32, torch.int64: B.CR_I64, torch.int32: B.CR_I32}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def rope_tables(dims: ModelDims, rows=None):
+    """bf16 cos/sin cache exactly as InternLM2DynamicNTKScalingRotaryEmbedding builds it at init
+    (reference InternVL/modeling_internlm2.py:154,213-229; returned in bf16 by :177-180).
+    Host-side setup (fp32 torch on CPU, like the reference), uploaded once as weights."""
+    rows = dims.max_pos if rows is None else rows
+    hd = dims.llm_head_dim
+    inv_freq = 1.0 / (dims.rope_theta ** (torch.arange(0, hd, 2).float() / hd))
+    t = torch.arange(rows).to(inv_freq.dtype)
+    freqs = torch.einsum('i,j->ij', t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(torch.bfloat16), emb.sin().to(torch.bfloat16)
+
+
+class Engine:
+    """One context per device (include/callireader_hip.h)."""
+
+    def __init__(self, dims: ModelDims = None, device=0, max_pos=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('callireader_amd needs a ROCm GPU: there is no CPU fallback for the hot path')
+        self.dims = dims or ModelDims.full()
+        self.device = torch.device('cuda', device)
+        self.max_pos = max_pos or self.dims.max_pos
+        d = B.ModelDesc(vit_layers=self.dims.vit_layers, rs_depth=self.dims.rs_depth, llm_layers=self.dims.llm_layers,
+                        vocab=self.dims.vocab, max_pos=self.max_pos, vit_ln_eps=self.dims.vit_ln_eps,
+                        rms_eps=self.dims.rms_eps)
+        h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        B.check(B.lib.cr_create(device, C.byref(d), C.byref(h)), 'cr_create')
+        self._h = h
+        self._kv = []
+
+    def close(self):
+        if getattr(self, '_h', None):
+            B.lib.cr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----
+    def load_weight(self, name, t):
+        t = t.detach().contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        B.check(B.lib.cr_load_weight(self._h, name.encode(), _p(t), _DT[t.dtype], shape, t.dim(),
+                                     0 if t.is_cuda else 1, _stream()), f'cr_load_weight({name})')
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()   # the source may be freed by the caller right after
+
+    def load_state_dict(self, sd):
+        for k, v in (sd.items() if hasattr(sd, 'items') else sd):
+            self.load_weight(k, v if v.dtype in (torch.bfloat16,) or not v.is_floating_point() else v.to(torch.bfloat16))
+
+    def load_rope(self):
+        cos, sin = rope_tables(self.dims, self.max_pos)
+        self.load_weight('rope.cos', cos)
+        self.load_weight('rope.sin', sin)
+
+    def finalize(self):
+        B.check(B.lib.cr_finalize(self._h, _stream()), 'cr_finalize')
+
+    # ---- vision ----
+    def _chk_pixels(self, px):
+        if px.dim() != 4:
+            raise ValueError(f'wrong pixel_values size: {px.shape}')       # modeling_intern_vit.py:417-420
+        if tuple(px.shape[1:]) != (3, self.dims.image_size, self.dims.image_size):
+            raise ValueError(f'pixel_values must be (T,3,448,448), got {tuple(px.shape)}')
+        return px.to(self.device, torch.bfloat16).contiguous()
+
+    def vit_forward(self, pixel_values):
+        px = self._chk_pixels(pixel_values)
+        T = px.shape[0]
+        out = torch.empty(T, self.dims.vit_tokens, self.dims.vit_hidden, device=self.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_vit_forward(self._h, _p(px), T, _p(out), _stream()), 'cr_vit_forward')
+        return out
+
+    def project(self, vit_out):
+        T = vit_out.shape[0]
+        vit_out = vit_out.contiguous()
+        out = torch.empty(T, self.dims.tokens_per_tile, self.dims.llm_hidden, device=self.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_project(self._h, _p(vit_out), T, _p(out), _stream()), 'cr_project')
+        return out
+
+    def extract_feature(self, pixel_values):
+        px = self._chk_pixels(pixel_values)
+        T = px.shape[0]
+        out = torch.empty(T, self.dims.tokens_per_tile, self.dims.llm_hidden, device=self.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_extract_feature(self._h, _p(px), T, _p(out), _stream()), 'cr_extract_feature')
+        return out
+
+    # ---- CalliAlign ----
+    def resample(self, feats):
+        feats = feats.contiguous()
+        T = feats.shape[0]
+        out = torch.empty(T, self.dims.rs_queries, self.dims.llm_hidden, device=self.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_resample(self._h, _p(feats), T, _p(out), _stream()), 'cr_resample')
+        return out
+
+    def vq(self, x, with_cos=False):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        n = x2.shape[0]
+        idx = torch.empty(n, device=self.device, dtype=torch.int64)
+        cos = torch.empty(n, device=self.device, dtype=torch.bfloat16) if with_cos else None
+        B.check(B.lib.cr_vq(self._h, _p(x2), n, _p(idx), _p(cos), _stream()), 'cr_vq')
+        idx = idx.reshape(x.shape[:-1])
+        return (idx, cos.reshape(x.shape[:-1])) if with_cos else idx
+
+    def denorm(self, x, idx, cos=None, drop_zero=False, hard_vq=False):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        n = x2.shape[0]
+        idx1 = idx.reshape(-1).contiguous()
+        out = torch.empty_like(x2)
+        n_out = torch.zeros(1, device=self.device, dtype=torch.int32)
+        flags = (1 if drop_zero else 0) | (2 if hard_vq else 0)
+        if hard_vq and cos is None:
+            raise ValueError('hard_vq needs the cosine values from vq(..., with_cos=True)')
+        cosr = cos.reshape(-1).contiguous() if cos is not None else None
+        B.check(B.lib.cr_denorm(self._h, _p(x2), _p(idx1), _p(cosr), n, flags, _p(out), _p(n_out), _stream()), 'cr_denorm')
+        return out[:int(n_out.item())] if drop_zero else out
+
+    # ---- language model ----
+    def embed_splice(self, input_ids, vit_embeds=None, ref_embeds=None, img_id=92546, ref_id=92537):
+        ids = input_ids.reshape(-1).to(self.device, torch.int64).contiguous()
+        S = ids.shape[0]
+        out = torch.empty(S, self.dims.llm_hidden, device=self.device, dtype=torch.bfloat16)
+        v = vit_embeds.reshape(-1, self.dims.llm_hidden).contiguous() if vit_embeds is not None else None
+        r = ref_embeds.reshape(-1, self.dims.llm_hidden).to(torch.bfloat16).contiguous() if ref_embeds is not None else None
+        B.check(B.lib.cr_embed_splice(self._h, _p(ids), S, _p(v), 0 if v is None else v.shape[0], img_id,
+                                      _p(r), 0 if r is None else r.shape[0], ref_id, _p(out), _stream()), 'cr_embed_splice')
+        return out
+
+    def kv_alloc(self, n_seqs, max_tokens):
+        h = C.c_void_p()
+        B.check(B.lib.cr_kv_alloc(self._h, n_seqs, max_tokens, C.byref(h)), 'cr_kv_alloc')
+        return KVCache(self, h, n_seqs, max_tokens)
+
+    def prefill(self, kv, seq, embeds, want_logits=False):
+        e = embeds.reshape(-1, self.dims.llm_hidden).contiguous()
+        S = e.shape[0]
+        logits = torch.empty(self.dims.vocab, device=self.device, dtype=torch.float32) if want_logits else None
+        nxt = torch.empty(1, device=self.device, dtype=torch.int64)
+        B.check(B.lib.cr_llm_prefill(self._h, kv._h, seq, _p(e), S, _p(logits), _p(nxt), _stream()), 'cr_llm_prefill')
+        return (nxt, logits) if want_logits else nxt
+
+    def decode(self, kv, seqs, tokens, penalty=1.0, history=None, hist_len=None, want_logits=False):
+        n = len(seqs)
+        seq_arr = (C.c_int32 * n)(*seqs)
+        tokens = tokens.reshape(-1).to(self.device, torch.int64).contiguous()
+        logits = torch.empty(n, self.dims.vocab, device=self.device, dtype=torch.float32) if want_logits else None
+        nxt = torch.empty(n, device=self.device, dtype=torch.int64)
+        if history is not None:
+            hl = (C.c_int32 * n)(*hist_len)
+            stride = history.shape[1]
+        else:
+            hl = (C.c_int32 * n)(*([0] * n))
+            stride = 0
+        B.check(B.lib.cr_llm_decode(self._h, kv._h, seq_arr, n, _p(tokens), _p(logits), float(penalty),
+                                    _p(history), stride, hl, _p(nxt), _stream()), 'cr_llm_decode')
+        return (nxt, logits) if want_logits else nxt
+
+
+class KVCache:
+    def __init__(self, eng, h, n_seqs, max_tokens):
+        self.eng, self._h, self.n_seqs, self.max_tokens = eng, h, n_seqs, max_tokens
+
+    def length(self, seq):
+        return B.lib.cr_kv_length(self._h, seq)
+
+    def reset(self, seq):
+        B.check(B.lib.cr_kv_reset(self._h, seq), 'cr_kv_reset')
+
+    def free(self):
+        if self._h:
+            B.lib.cr_kv_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- single operators (tests / profiling) ----
+def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None):
+    M, K = A.shape
+    N = Wt.shape[0]
+    ncols = n_out if n_out is not None else (N // 2 if epi == 4 else N)
+    mrows = M if epi != 5 else (M // group) * (group + 1)
+    Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
+    B.check(B.lib.cr_op_gemm(epi, _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
+                             _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')
+    return Cc
+
+
+def op_layernorm(x, gamma, beta, eps, pixel_shuffle=False):
+    if pixel_shuffle:
+        T = x.shape[0]
+        out = torch.empty(T * 256, 4096, device=x.device, dtype=torch.bfloat16)
+        rows, n = T * 256, 4096
+    else:
+        out = torch.empty_like(x)
+        rows, n = x.shape[0], x.shape[1]
+    B.check(B.lib.cr_op_layernorm(_p(x), _p(out), _p(gamma), _p(beta), rows, n, eps, 1 if pixel_shuffle else 0, _stream()),
+            'cr_op_layernorm')
+    return out
+
+
+def op_rmsnorm(x, gamma, eps):
+    out = torch.empty_like(x)
+    B.check(B.lib.cr_op_rmsnorm(_p(x), _p(out), _p(gamma), x.shape[0], x.shape[1], eps, _stream()), 'cr_op_rmsnorm')
+    return out
+
+
+def op_attention(q, k, v, o, strides, Bn, H, Sq, Sk, head_dim, kv_group=1, causal=False, q_pos0=0, q_prescale=1.0, s_div=1.0):
+    st = (C.c_int64 * 12)(*strides)
+    B.check(B.lib.cr_op_attention(_p(q), _p(k), _p(v), _p(o), st, Bn, H, Sq, Sk, head_dim, kv_group, 1 if causal else 0,
+                                  q_pos0, q_prescale, s_div, _stream()), 'cr_op_attention')
+    return o

@@ -1,0 +1,130 @@
+/* callireader_hip.h — C ABI of libcallireader_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for CalliReader's image->text hot path.  The reference is pure
+ * Python; each entry point replaces the PyTorch module call named next to it
+ * (paths relative to the reference repo).  The Python binding a maintainer would
+ * add is shown in INTEGRATION.md and shipped as callireader_amd/_binding.py.
+ *
+ * Conventions
+ *   - every pointer argument is a DEVICE pointer owned by the caller unless it is
+ *     documented as host; buffers are dense row-major bf16 unless stated;
+ *   - every launch takes a hipStream_t (passed as void*); calls only enqueue work,
+ *     except cr_create/cr_destroy/cr_load_weight/cr_finalize/cr_kv_alloc/cr_kv_free,
+ *     which may allocate and synchronise;
+ *   - return value: 0 = CR_OK, negative = error; cr_last_error() returns a
+ *     thread-local, NUL-terminated description of the last failure;
+ *   - no exceptions cross the ABI, no internal threads, one context per device,
+ *     a context is not re-entrant.
+ */
+#ifndef CALLIREADER_HIP_H
+#define CALLIREADER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CR_ABI_VERSION 1
+
+enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
+enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3 };
+
+typedef struct cr_ctx cr_ctx;
+typedef struct cr_kv cr_kv;
+
+/* Shapes: InternVL/config.json (vision_config :114-143, llm_config :14-103, downsample_ratio :11),
+ * models/perceiver_resampler.py:54-64, InternVL/modeling_internvl_chat.py:157. */
+typedef struct cr_model_desc {
+    int32_t vit_layers;     /* 24  */
+    int32_t rs_depth;       /* 4   */
+    int32_t llm_layers;     /* 32  */
+    int32_t vocab;          /* 92553 */
+    int32_t max_pos;        /* rows of the RoPE tables handed over by the host (<= 32768) */
+    float vit_ln_eps;       /* 1e-6 */
+    float rms_eps;          /* 1e-5 */
+    int32_t reserved[8];
+} cr_model_desc;
+
+const char* cr_last_error(void);
+int cr_abi_version(void);
+
+/* ---- lifetime & weights --------------------------------------------------------------------- */
+/* InternVLChatModel.__init__ (InternVL/modeling_internvl_chat.py:136-194) */
+int cr_create(int device, const cr_model_desc* desc, cr_ctx** out);
+int cr_destroy(cr_ctx* ctx);
+/* One call per checkpoint tensor; `name` is the safetensors key (InternVL/model.safetensors.index.json), or
+ *   "calli.mu" / "calli.sigma"  (vocab,1)  — params/gauss_norm_mu_sigma.pth columns (modeling_internvl_chat.py:153-155)
+ *   "rope.cos" / "rope.sin"     (max_pos,128) bf16 — InternLM2DynamicNTKScalingRotaryEmbedding cache
+ *                                (InternVL/modeling_internlm2.py:213-229), built on the host exactly as the reference does.
+ * The library copies (and may re-layout) the data; `src_is_host` selects H2D vs D2D. */
+int cr_load_weight(cr_ctx* ctx, const char* name, const void* src, int dtype, const int64_t* shape, int ndim,
+                   int src_is_host, void* stream);
+/* Build derived tensors once all weights are in (K-padded patch kernel, interleaved w1|w3, L2-normalised VQ table). */
+int cr_finalize(cr_ctx* ctx, void* stream);
+
+/* ---- vision ---------------------------------------------------------------------------------- */
+/* InternVisionModel.forward(pixel_values).last_hidden_state — InternVL/modeling_intern_vit.py:399-437
+ * pixels [T,3,448,448] -> out [T,1025,1024] */
+int cr_vit_forward(cr_ctx* ctx, const void* pixels, int T, void* out, void* stream);
+/* drop CLS + pixel_shuffle(0.5, v2) + mlp1 — InternVL/modeling_internvl_chat.py:283-297,311-318
+ * vit_out [T,1025,1024] -> out [T,256,4096] */
+int cr_project(cr_ctx* ctx, const void* vit_out, int T, void* out, void* stream);
+/* InternVLChatModel.extract_feature — InternVL/modeling_internvl_chat.py:299-319 (= the two calls above) */
+int cr_extract_feature(cr_ctx* ctx, const void* pixels, int T, void* out, void* stream);
+
+/* ---- CalliAlign ------------------------------------------------------------------------------- */
+/* PerceiverResampler.forward — models/perceiver_resampler.py:81-100:  in [T,256,4096] -> out [T,3,4096] */
+int cr_resample(cr_ctx* ctx, const void* in, int T, void* out, void* stream);
+/* vq_cos_sim — models/similarity.py:9-27:  in [n,4096] -> idx [n] int64, cos [n] bf16 (cos may be NULL) */
+int cr_vq(cr_ctx* ctx, const void* in, int n, int64_t* idx, void* cos, void* stream);
+/* calli_align tail — InternVL/modeling_internvl_chat.py:602-640.
+ * flags bit0 = drop_zero, bit1 = hard_vq (needs cos).  out [n,4096]; *n_out (device int32) = rows kept. */
+int cr_denorm(cr_ctx* ctx, const void* in, const int64_t* idx, const void* cos, int n, int flags,
+              void* out, int32_t* n_out, void* stream);
+
+/* ---- language model --------------------------------------------------------------------------- */
+/* generate_ocr / generate_origin head — InternVL/modeling_internvl_chat.py:1081-1107,1033-1052:
+ * out[s] = tok_embeddings[ids[s]], rows with ids == img_id overwritten by vit_embeds (in order),
+ * rows with ids == ref_id by ref_embeds.  n_vit / n_ref rows must equal the id counts (checked on the host side). */
+int cr_embed_splice(cr_ctx* ctx, const int64_t* ids, int S, const void* vit_embeds, int n_vit, int64_t img_id,
+                    const void* ref_embeds, int n_ref, int64_t ref_id, void* out, void* stream);
+
+/* KV cache for `n_seqs` sequences of up to `max_tokens` tokens: replaces the reference's tuple cache grown by
+ * torch.cat (InternVL/modeling_internlm2.py:383-388). */
+int cr_kv_alloc(cr_ctx* ctx, int n_seqs, int max_tokens, cr_kv** out);
+int cr_kv_free(cr_kv* kv);
+int cr_kv_length(const cr_kv* kv, int seq);           /* tokens currently held (host-side bookkeeping) */
+int cr_kv_reset(cr_kv* kv, int seq);
+
+/* InternLM2ForCausalLM.forward(inputs_embeds=…, use_cache=True) — InternVL/modeling_internlm2.py:1022-1110,
+ * for ONE sequence `seq` of the cache, appended at its current length.  embeds [S,4096].
+ * last_logits [vocab] fp32 (may be NULL), next_token: device int64 = argmax of the last row (first max wins). */
+int cr_llm_prefill(cr_ctx* ctx, cr_kv* kv, int seq, const void* embeds, int S, float* last_logits,
+                   int64_t* next_token, void* stream);
+/* One greedy step for sequences seqs[0..n) (host int array): embeds tokens[i] (device int64), appends to the cache,
+ * logits [n,vocab] fp32 (may be NULL), applies HF RepetitionPenaltyLogitsProcessor over `history`
+ * (device int64 [n, hist_stride], hist_len[i] valid entries each, host array) when penalty != 1, writes
+ * next_tokens[i] = argmax.  Replaces one iteration of transformers 4.45.2 GenerationMixin._sample as driven from
+ * InternVL/modeling_internvl_chat.py:1111-1120. */
+int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int64_t* tokens, float* logits,
+                  float penalty, const int64_t* history, int hist_stride, const int32_t* hist_len,
+                  int64_t* next_tokens, void* stream);
+
+/* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
+/* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32 */
+int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+               const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
+               void* stream);
+int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* beta, int64_t rows, int n, float eps,
+                    int pixel_shuffle, void* stream);
+int cr_op_rmsnorm(const void* in, void* out, const void* gamma, int64_t rows, int n, float eps, void* stream);
+/* q/k/v/o addressed as base + b*bs + row*rs + head*hs (elements) */
+int cr_op_attention(const void* q, const void* k, const void* v, void* o, const int64_t* strides12, int B, int H,
+                    int Sq, int Sk, int head_dim, int kv_group, int causal, int q_pos0, float q_prescale, float s_div,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALLIREADER_HIP_H */

@@ -1,0 +1,251 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (cr_op_*).
+
+References are plain PyTorch fp32 expressions of the same op with the reference
+model's bf16 rounding points written out.  Tolerances: outputs are bf16, so one
+output ulp is 2^-8 relative; we allow 2 ulp (rtol 1.6e-2) plus an absolute floor
+for cancellation.  Integer-valued cases are exact (atol = rtol = 0): they catch
+fragment-layout and swizzle mistakes that random data can hide.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1.6e-2
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rb(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.fixture(scope='module')
+def E():
+    from callireader_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 64), (128, 128, 128), (1, 128, 64), (257, 384, 192), (1025, 1024, 640)])
+def test_gemm_exact_integers(E, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randint(-1, 2, (M, K), generator=g).float()
+    W = torch.randint(-1, 2, (N, K), generator=g).float()
+    # asymmetric content: make row i of A and row j of W identifiable
+    A[:, 0] = (torch.arange(M) % 3 - 1).float()
+    W[:, 1] = (torch.arange(N) % 2).float()
+    ref = A @ W.t()
+    assert ref.abs().max() <= 256
+    out = E.op_gemm(0, bf(A).to(dev()), bf(W).to(dev()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), ref)
+
+
+def _rand(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize('M,N,K', [(515, 384, 256), (2050, 1024, 1024)])
+def test_gemm_epilogues(E, M, N, K):
+    g = torch.Generator().manual_seed(1)
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.05)).to(dev())
+    bias = bf(_rand((N,), g, 0.1)).to(dev())
+    scale = bf(_rand((N,), g, 0.2) + 0.1).to(dev())
+    res = bf(_rand((M, N), g)).to(dev())
+    acc = A.float() @ W.float().t()
+    lin = rb(acc + bias.float())
+    atol = 2e-2
+
+    def close(out, ref):
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=atol)
+
+    close(E.op_gemm(0, A, W, bias=bias), lin)
+    close(E.op_gemm(0, A, W), rb(acc))
+    close(E.op_gemm(1, A, W, bias=bias), rb(torch.nn.functional.gelu(lin)))
+    close(E.op_gemm(2, A, W, bias=bias, scale=scale, res=res), rb(res.float() + rb(lin * scale.float())))
+    close(E.op_gemm(3, A, W, bias=bias, res=res), rb(res.float() + lin))
+    out32 = E.op_gemm(6, A, W, out_dtype=torch.float32)
+    close(out32, rb(acc))
+    assert out32.dtype == torch.float32
+    # in-place residual (C aliases res), as the ViT / LLM residual stream uses it
+    x = res.clone()
+    from callireader_amd import _binding as B
+    from callireader_amd.engine import _p, _stream
+    B.check(B.lib.cr_op_gemm(2, _p(A), K, _p(W), K, _p(x), N, _p(bias), _p(scale), _p(x), N, M, N, K, 0, _stream()))
+    close(x, rb(res.float() + rb(lin * scale.float())))
+
+
+def test_gemm_swiglu(E):
+    g = torch.Generator().manual_seed(2)
+    M, F, K = 300, 512, 256
+    A = bf(_rand((M, K), g)).to(dev())
+    w1 = bf(_rand((F, K), g, 0.05))
+    w3 = bf(_rand((F, K), g, 0.05))
+    # interleave [8 rows of w1 | 8 rows of w3] as llm_finalize does
+    W = torch.stack([w1.reshape(F // 8, 8, K), w3.reshape(F // 8, 8, K)], dim=1).reshape(2 * F, K).to(dev())
+    gte = rb(A.float() @ w1.float().t().to(dev()))
+    up = rb(A.float() @ w3.float().t().to(dev()))
+    ref = rb(rb(torch.nn.functional.silu(gte)) * up)
+    out = E.op_gemm(4, A, W)
+    torch.cuda.synchronize()
+    assert out.shape == (M, F)
+    torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=2e-2)
+
+
+def test_gemm_patch_rows(E):
+    g = torch.Generator().manual_seed(3)
+    T, G, N, K = 2, 1024, 256, 128
+    A = bf(_rand((T * G, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.05)).to(dev())
+    bias = bf(_rand((N,), g, 0.1)).to(dev())
+    pos = bf(_rand((G + 1, N), g)).to(dev())
+    out = E.op_gemm(5, A, W, bias=bias, res=pos, group=G)
+    torch.cuda.synchronize()
+    lin = rb(A.float() @ W.float().t() + bias.float()).reshape(T, G, N)
+    ref = rb(lin + pos.float()[1:][None])
+    got = out.float().reshape(T, G + 1, N)
+    torch.testing.assert_close(got[:, 1:], ref, rtol=RTOL, atol=2e-2)
+    assert torch.equal(got[:, 0], torch.zeros(T, N, device=dev()))      # CLS rows are not this kernel's
+
+
+def test_gemm_ragged_n_and_f32(E):
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 70, 1003, 128           # N not a multiple of 8 (like vocab 92553)
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.05)).to(dev())
+    out = E.op_gemm(6, A, W, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, rb(A.float() @ W.float().t()), rtol=RTOL, atol=2e-2)
+
+
+def test_gemm_rejects_bad_k(E):
+    A = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
+    W = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
+    from callireader_amd._binding import CalliReaderError
+    with pytest.raises(CalliReaderError):
+        E.op_gemm(0, A, W)
+
+
+@pytest.mark.parametrize('rows,n', [(1025 * 2, 1024), (5, 1024), (777, 4096)])
+def test_layernorm(E, rows, n):
+    g = torch.Generator().manual_seed(5)
+    x = bf(_rand((rows, n), g) * 2 + 0.3).to(dev())
+    gamma = bf(_rand((n,), g, 0.1) + 1).to(dev())
+    beta = bf(_rand((n,), g, 0.1)).to(dev())
+    out = E.op_layernorm(x, gamma, beta, 1e-6)
+    torch.cuda.synchronize()
+    ref = rb(torch.nn.functional.layer_norm(x.float(), (n,), gamma.float(), beta.float(), 1e-6))
+    torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=1e-2)
+
+
+def test_layernorm_pixel_shuffle(E):
+    from oracle import vision
+    g = torch.Generator().manual_seed(6)
+    T = 3
+    v = bf(_rand((T, 1025, 1024), g))
+    gamma = bf(_rand((4096,), g, 0.1) + 1)
+    beta = bf(_rand((4096,), g, 0.1))
+    out = E.op_layernorm(v.to(dev()), gamma.to(dev()), beta.to(dev()), 1e-5, pixel_shuffle=True)
+    torch.cuda.synchronize()
+    x = v[:, 1:, :].reshape(T, 32, 32, 1024)
+    x = vision.pixel_shuffle(x, 0.5).reshape(T * 256, 4096)
+    ref = rb(torch.nn.functional.layer_norm(x.float(), (4096,), gamma.float(), beta.float(), 1e-5))
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=RTOL, atol=1e-2)
+
+
+def test_rmsnorm(E):
+    g = torch.Generator().manual_seed(7)
+    x = bf(_rand((333, 4096), g) * 3).to(dev())
+    w = bf(_rand((4096,), g, 0.1) + 1).to(dev())
+    out = E.op_rmsnorm(x, w, 1e-5)
+    torch.cuda.synchronize()
+    xf = x.float()
+    h = rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    torch.testing.assert_close(out.float(), rb(w.float() * h), rtol=RTOL, atol=1e-2)
+
+
+def _attn_ref(q, k, v, causal, q_pos0, prescale, s_div):
+    """q (B,H,Sq,D), k/v (B,H,Sk,D) float tensors holding bf16 values; reference rounding points."""
+    if prescale != 1.0:
+        q = rb(q * prescale)
+    s = rb(q @ k.transpose(-1, -2))
+    if s_div != 1.0:
+        s = rb(s / s_div)
+    if causal:
+        Sq, Sk = s.shape[-2:]
+        qpos = q_pos0 + torch.arange(Sq, device=s.device)[:, None]
+        s = s.masked_fill(torch.arange(Sk, device=s.device)[None, :] > qpos, float('-inf'))
+    p = rb(torch.softmax(s, dim=-1))
+    return rb(p @ v)
+
+
+def test_attention_vit_shape(E):
+    g = torch.Generator().manual_seed(8)
+    Bn, S, H, D = 2, 1025, 16, 64
+    qkv = bf(_rand((Bn, S, 3 * H * D), g)).to(dev())
+    o = torch.zeros(Bn, S, H * D, device=dev(), dtype=torch.bfloat16)
+    C3, C1 = 3 * H * D, H * D
+    E.op_attention(qkv, qkv[:, :, C1:], qkv[:, :, 2 * C1:], o,
+                   [S * C3, C3, D, S * C3, C3, D, S * C3, C3, D, S * C1, C1, D], Bn, H, S, S, D, q_prescale=0.125)
+    torch.cuda.synchronize()
+    t = qkv.float().reshape(Bn, S, 3, H, D).permute(2, 0, 3, 1, 4)
+    ref = _attn_ref(t[0], t[1], t[2], False, 0, 0.125, 1.0).transpose(1, 2).reshape(Bn, S, C1)
+    torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
+
+
+def test_attention_exact_identity_layout(E):
+    """V = one-hot rows, uniform scores: output row = mean of V rows -> exact in bf16; catches V^T/tr-read mistakes."""
+    Bn, S, H, D = 1, 64, 1, 64
+    q = torch.zeros(Bn, S, H * D, device=dev(), dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    v = torch.zeros_like(q)
+    for key in range(S):
+        v[0, key, key % D] = float(key % 7 + 1) * 64.0     # asymmetric in (key, d)
+    o = torch.zeros_like(q)
+    E.op_attention(q, k, v, o, [S * D, D, D] * 4, Bn, H, S, S, D)
+    torch.cuda.synchronize()
+    ref = v.float().mean(dim=1, keepdim=True).expand(-1, S, -1)
+    torch.testing.assert_close(o.float(), rb(ref), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('Sq,Sk,q_pos0', [(300, 300, 0), (1, 77, 76), (130, 200, 70)])
+def test_attention_llm_causal_gqa(E, Sq, Sk, q_pos0):
+    g = torch.Generator().manual_seed(9 + Sq)
+    H, KV, D = 8, 2, 128
+    q = bf(_rand((Sq, H * D), g)).to(dev())
+    k = bf(_rand((KV, Sk, D), g)).to(dev())
+    v = bf(_rand((KV, Sk, D), g)).to(dev())
+    o = torch.zeros(Sq, H * D, device=dev(), dtype=torch.bfloat16)
+    E.op_attention(q, k, v, o, [0, H * D, D, 0, D, Sk * D, 0, D, Sk * D, 0, H * D, D], 1, H, Sq, Sk, D,
+                   kv_group=H // KV, causal=True, q_pos0=q_pos0, s_div=math.sqrt(D))
+    torch.cuda.synchronize()
+    qf = q.float().reshape(Sq, H, D).permute(1, 0, 2)[None]
+    kf = k.float().repeat_interleave(H // KV, dim=0)[None]
+    vf = v.float().repeat_interleave(H // KV, dim=0)[None]
+    ref = _attn_ref(qf, kf, vf, True, q_pos0, 1.0, math.sqrt(D))[0].permute(1, 0, 2).reshape(Sq, H * D)
+    torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
+
+
+def test_attention_softmax_spike(E):
+    """One key dominates late in the sequence: forces the online-softmax rescale branch."""
+    g = torch.Generator().manual_seed(11)
+    Bn, S, H, D = 1, 512, 1, 64
+    q = bf(_rand((Bn, S, D), g)).to(dev())
+    k = bf(_rand((Bn, S, D), g)).to(dev())
+    v = bf(_rand((Bn, S, D), g)).to(dev())
+    k[0, 400] = q[0, 5] * 4.0
+    o = torch.zeros_like(q)
+    E.op_attention(q, k, v, o, [S * D, D, D] * 4, Bn, H, S, S, D)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q.float()[:, None], k.float()[:, None], v.float()[:, None], False, 0, 1.0, 1.0)[:, 0]
+    torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
