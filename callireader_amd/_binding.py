@@ -41,8 +41,9 @@ SIGNATURES = {
     'cr_kv_free': (i32, [vp]),
     'cr_kv_length': (i32, [vp, i32]),
     'cr_kv_reset': (i32, [vp, i32]),
-    'cr_llm_prefill': (i32, [vp, vp, i32, vp, i32, vp, vp, vp]),
-    'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, vp, f32, vp, i32, C.POINTER(C.c_int32), vp, vp]),
+    'cr_kv_generated': (i32, [vp, i32, C.POINTER(i64), i32, vp]),
+    'cr_llm_prefill': (i32, [vp, vp, i32, vp, i32, f32, vp, vp]),
+    'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, f32, vp, vp]),
     'cr_op_gemm': (i32, [i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     'cr_op_layernorm': (i32, [vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     'cr_op_rmsnorm': (i32, [vp, vp, vp, i64, i32, f32, vp]),

@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     const int l31 = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
     const int kvh = head / p.kv_group;
+    const int slot = p.seq_map ? p.seq_map[batch] : batch;
+    const int Sk = p.sk_arr ? p.sk_arr[slot] + p.sk_add : p.Sk;
     const int qi = qb * 128 + wave * 32 + l31;
     const int qi_c = min(qi, p.Sq - 1);
 
@@ -58,15 +60,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         }
     }
 
-    const bf16* Kb = p.K + (int64_t)batch * p.k_bs + (int64_t)kvh * p.k_hs;
-    const bf16* Vb = p.V + (int64_t)batch * p.v_bs + (int64_t)kvh * p.v_hs;
+    const bf16* Kb = p.K + (int64_t)slot * p.k_bs + (int64_t)kvh * p.k_hs;
+    const bf16* Vb = p.V + (int64_t)slot * p.v_bs + (int64_t)kvh * p.v_hs;
 
     auto stage = [&](int buf, int kt) {
 #pragma unroll
         for (int ii = 0; ii < IPW; ii++) {
             const int r = (wave * IPW + ii) * RPI + lane / CPR;
             const int cp = lane % CPR;
-            const int key = min(kt * 64 + r, p.Sk - 1);
+            const int key = min(kt * 64 + r, Sk - 1);
             const bf16* ks = Kb + (int64_t)key * p.k_rs + ((cp ^ kswz<D>(r)) * 8);
             const bf16* vs = Vb + (int64_t)key * p.v_rs + ((cp ^ vswz<D>(r)) * 8);
             char* dst = smem + buf * (2 * TILE) + (wave * IPW + ii) * 1024;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         }
     };
 
-    int nt = (p.Sk + 63) / 64;
+    int nt = (Sk + 63) / 64;
     if (CAUSAL) {
         const int kmax = p.q_pos0 + min(qb * 128 + 127, p.Sq - 1);
         nt = min(nt, kmax / 64 + 1);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
                 float s = rbf(sacc[kb][e]);
                 if (p.s_div != 1.0f) s = rbf(s / p.s_div);
                 const int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const bool ok = key < p.Sk && (!CAUSAL || key <= qpos);
+                const bool ok = key < Sk && (!CAUSAL || key <= qpos);
                 s = ok ? s : -INFINITY;
                 sacc[kb][e] = s;
                 mloc = fmaxf(mloc, s);
@@ -206,7 +208,7 @@ int launch_t(const AttnParams& p, hipStream_t stream) {
 }  // namespace
 
 int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream) {
-    if (p.Sq <= 0 || p.Sk <= 0 || p.H <= 0 || p.B <= 0 || p.kv_group <= 0) return CR_ERR_ARG;
+    if (p.Sq <= 0 || (p.Sk <= 0 && !p.sk_arr) || p.H <= 0 || p.B <= 0 || p.kv_group <= 0) return CR_ERR_ARG;
     if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7) || (p.o_rs & 3)) return CR_ERR_ARG;
     if (head_dim == 64) return causal ? launch_t<64, true>(p, stream) : launch_t<64, false>(p, stream);
     if (head_dim == 128) return causal ? launch_t<128, true>(p, stream) : launch_t<128, false>(p, stream);

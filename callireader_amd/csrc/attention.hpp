@@ -13,6 +13,10 @@ struct AttnParams {
     int q_pos0;          // causal: absolute position of query row 0 (keys start at position 0)
     float q_prescale;    // multiply q in bf16 before Q.K^T (ViT: 64^-0.5, exact); 1 = off
     float s_div;         // divide bf16-rounded scores (LLM: sqrt(128)); 1 = off
+    // batched decode over a KV cache: batch b reads cache slot seq_map[b] (or b) holding sk_arr[slot] + sk_add keys
+    const int32_t* seq_map;
+    const int32_t* sk_arr;
+    int sk_add;
 };
 
 int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream);

@@ -1,0 +1,290 @@
+// CalliAlign stage: PerceiverResampler, cosine VQ, de-normalisation.
+//   reference: models/perceiver_resampler.py:8-100,130-141; models/similarity.py:9-27;
+//              InternVL/modeling_internvl_chat.py:602-640
+#include "ctx.hpp"
+#include "misc.hpp"
+#include "norm.hpp"
+
+namespace {
+
+constexpr int D = 4096, NQ = 3, NKV = 259, INNER = 512, HEADS = 8, DH = 64;
+
+// learns[t*3 + i][:] = resampler.learns[i][:]      (perceiver_resampler.py:92)
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int rows_src, int64_t rows_dst) {
+    const int64_t r = blockIdx.x;
+    if (r >= rows_dst) return;
+    const bf16x8* s = (const bf16x8*)(src + (int64_t)(r % rows_src) * D);
+    bf16x8* d = (bf16x8*)(dst + r * D);
+    d[threadIdx.x] = s[threadIdx.x];
+    d[threadIdx.x + 256] = s[threadIdx.x + 256];
+}
+
+// One wave per (tile, head): 3 queries x 259 keys x 64 dims, with the reference's exact rounding sequence
+// (perceiver_resampler.py:43-51): q*scale (bf16, exact), sim -> bf16, sim - amax -> bf16, softmax -> bf16, attn@v -> bf16.
+__global__ __launch_bounds__(64) void perceiver_attn_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv,
+                                                            bf16* __restrict__ out, float scale) {
+    __shared__ float qs[NQ][DH];
+    __shared__ float ps[NQ][320];
+    const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) qs[i][lane] = rbf(bf2f(q[((int64_t)t * NQ + i) * INNER + h * DH + lane]) * scale);
+    __syncthreads();
+    const bf16* kb = kv + (int64_t)t * NKV * (2 * INNER) + h * DH;
+    const bf16* vb = kb + INNER;
+    float s[NQ][5];
+    float mx[NQ] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kk = 0; kk < 5; kk++) {
+        const int key = lane + 64 * kk;
+        const bool ok = key < NKV;
+        const bf16* kr = kb + (int64_t)(ok ? key : 0) * (2 * INNER);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const bf16x8 kc = *(const bf16x8*)(kr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float kf = bf2f(kc[e]);
+                a0 += qs[0][c * 8 + e] * kf; a1 += qs[1][c * 8 + e] * kf; a2 += qs[2][c * 8 + e] * kf;
+            }
+        }
+        s[0][kk] = ok ? rbf(a0) : -INFINITY; s[1][kk] = ok ? rbf(a1) : -INFINITY; s[2][kk] = ok ? rbf(a2) : -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NQ; i++) mx[i] = fmaxf(mx[i], s[i][kk]);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const float m = wave_max(mx[i]);
+        float e[5], sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) {
+            const float d = rbf(s[i][kk] - m);            // sim - amax in bf16; its own max is exactly 0
+            e[kk] = (lane + 64 * kk < NKV) ? __expf(d) : 0.f;
+            sum += e[kk];
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) ps[i][lane + 64 * kk] = rbf(e[kk] / sum);
+    }
+    __syncthreads();
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int key = 0; key < NKV; key++) {
+        const float vf = bf2f(vb[(int64_t)key * (2 * INNER) + lane]);
+        o0 += ps[0][key] * vf; o1 += ps[1][key] * vf; o2 += ps[2][key] * vf;
+    }
+    bf16* ob = out + (int64_t)t * NQ * INNER + h * DH + lane;
+    ob[0] = f2bf(o0); ob[INNER] = f2bf(o1); ob[2 * INNER] = f2bf(o2);
+}
+
+// F.normalize(x, p=2, dim=-1) on bf16 rows of 4096 (similarity.py:17-18):
+//   n = bf16(sqrt(sum x^2)); y = bf16(x / max(n, 1e-12))
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int64_t rows) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bf16x8 a = *(const bf16x8*)(in + r * D + tid * 16), b = *(const bf16x8*)(in + r * D + tid * 16 + 8);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s += bf2f(a[e]) * bf2f(a[e]); s += bf2f(b[e]) * bf2f(b[e]); }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float n = fmaxf(rbf(sqrtf(red[0] + red[1] + red[2] + red[3])), 1e-12f);
+    bf16x8 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { oa[e] = f2bf(bf2f(a[e]) / n); ob[e] = f2bf(bf2f(b[e]) / n); }
+    *(bf16x8*)(out + r * D + tid * 16) = oa;
+    *(bf16x8*)(out + r * D + tid * 16 + 8) = ob;
+}
+
+// similarity.max(dim=-1): first maximal index wins (torch semantics)
+__global__ __launch_bounds__(256) void row_argmax_bf16_kernel(const bf16* __restrict__ sim, int64_t ld, int n_cols,
+                                                              int64_t* __restrict__ idx, bf16* __restrict__ cosv) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    float best = -INFINITY; int besti = 0x7fffffff;
+    for (int c = tid; c < n_cols; c += 256) {
+        const float v = bf2f(sim[r * ld + c]);
+        if (v > best) { best = v; besti = c; }
+    }
+    bv[tid] = best; bi[tid] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v2 = bv[tid + o]; const int i2 = bi[tid + o];
+            if (v2 > bv[tid] || (v2 == bv[tid] && i2 < bi[tid])) { bv[tid] = v2; bi[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { idx[r] = bi[0]; if (cosv) cosv[r] = f2bf(bv[0]); }
+}
+
+// calli_align tail (modeling_internvl_chat.py:602-640): row compaction for drop_zero (order-preserving; n is a few
+// hundred, one thread scans), then one workgroup per kept row.
+__global__ void denorm_index_kernel(const int64_t* __restrict__ idx, int n, int flags, int32_t* __restrict__ n_out,
+                                    int32_t* __restrict__ dst_row) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int k = 0;
+    for (int r = 0; r < n; r++) {
+        const bool keep = !(flags & 1) || idx[r] != 0;
+        dst_row[r] = keep ? k : -1;
+        k += keep ? 1 : 0;
+    }
+    *n_out = k;
+}
+
+template <bool PARAMS_F32>
+__global__ __launch_bounds__(256) void denorm_kernel(const bf16* __restrict__ x, const int64_t* __restrict__ idx,
+                                                     const bf16* __restrict__ cosv, const bf16* __restrict__ table,
+                                                     const void* __restrict__ mu, const void* __restrict__ sigma,
+                                                     int flags, bf16* __restrict__ out, const int32_t* __restrict__ dst_row) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int dr = dst_row[r];
+    if (dr < 0) return;
+    const int64_t id = idx[r];
+    // hard VQ: below = (cos <= 0.5); x*(1-below) + table[idx]*below selects one of the two rows (:609-614)
+    const bool hard = (flags & 2) && bf2f(cosv[r]) <= 0.5f;
+    const bf16* src = hard ? table + id * D : x + (int64_t)r * D;
+    for (int c = tid; c < D; c += 256) {
+        const float xv = bf2f(src[c]);
+        float y;
+        if (PARAMS_F32) y = xv * ((const float*)sigma)[id] + ((const float*)mu)[id];
+        else y = rbf(xv * bf2f(((const bf16*)sigma)[id])) + bf2f(((const bf16*)mu)[id]);
+        out[(int64_t)dr * D + c] = f2bf(y);
+    }
+}
+
+int gemm(int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
+         const bf16* res, int64_t ldr, int M, int N, int K, hipStream_t st) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.res = res; p.ldr = ldr;
+    p.M = M; p.N = N; p.K = K;
+    int r = launch_gemm(epi, p, st);
+    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) failed", epi, M, N, K);
+    return CR_OK;
+}
+
+int ln(const bf16* in, bf16* out, const bf16* g, const bf16* b, int64_t rows, int in_group, int out_group, int out_off, hipStream_t st) {
+    NormParams np{};
+    np.in = in; np.ld_in = D; np.out = out; np.ld_out = D; np.gamma = g; np.beta = b; np.rows = rows; np.eps = 1e-5f;
+    np.in_group = in_group; np.out_group = out_group; np.out_off = out_off;
+    return launch_layernorm(np, D, 0, st);
+}
+
+}  // namespace
+
+int calli_finalize(cr_ctx* c, hipStream_t st) {
+    const DevTensor* tb = WT(c, "normed_emb.weight");
+    if (!tb) return CR_ERR_STATE;
+    if (tb->shape.size() != 2 || tb->shape[1] != D) return cr_fail(CR_ERR_ARG, "normed_emb.weight must be [vocab,4096]");
+    DevTensor t;
+    t.dtype = CR_BF16; t.shape = tb->shape; t.bytes = tb->bytes;
+    auto it = c->w.find("derived.vq_table");
+    if (it != c->w.end() && it->second.bytes == t.bytes) t.ptr = it->second.ptr;
+    else CR_HIP(hipMalloc(&t.ptr, t.bytes));
+    // F.normalize(embedding_weight, p=2, dim=1) is input-independent: do it once (similarity.py:18 does it per call)
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)tb->shape[0]), dim3(256), 0, st, (const bf16*)tb->ptr, (bf16*)t.ptr, tb->shape[0]);
+    CR_HIP(hipGetLastError());
+    c->w["derived.vq_table"] = t;
+    return CR_OK;
+}
+
+extern "C" {
+
+int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
+    if (!c || !in || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_resample: bad argument");
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t R = (int64_t)T * NQ;
+    const size_t need = ((size_t)T * NKV * D + (size_t)T * NKV * 2 * INNER + (size_t)R * D * 3 + (size_t)R * INNER * 2 +
+                         (size_t)R * D * 4) * 2 + 8192;
+    CR_TRY(ws_ensure(c, need));
+    Arena ar(c->ws);
+    bf16* kv_in = ar.take<bf16>((size_t)T * NKV * D);
+    bf16* kv = ar.take<bf16>((size_t)T * NKV * 2 * INNER);
+    bf16* learns = ar.take<bf16>((size_t)R * D);
+    bf16* lnl = ar.take<bf16>((size_t)R * D);
+    bf16* q = ar.take<bf16>((size_t)R * INNER);
+    bf16* ao = ar.take<bf16>((size_t)R * INNER);
+    bf16* ff = ar.take<bf16>((size_t)R * D * 4);
+    const bf16* x = (const bf16*)in;
+
+    const bf16* l0 = W(c, "resampler.learns");
+    if (!l0) return CR_ERR_STATE;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)R), dim3(256), 0, st, l0, learns, NQ, R);
+
+    for (int l = 0; l < c->d.rs_depth; l++) {
+        const std::string a = "resampler.layers." + std::to_string(l) + ".0.";
+        const std::string f = "resampler.layers." + std::to_string(l) + ".1.net.";
+        const bf16 *nmw = W(c, a + "norm_media.weight"), *nmb = W(c, a + "norm_media.bias");
+        const bf16 *nlw = W(c, a + "norm_learns.weight"), *nlb = W(c, a + "norm_learns.bias");
+        const bf16 *wq = W(c, a + "to_q.weight"), *wkv = W(c, a + "to_kv.weight"), *wo = W(c, a + "to_out.weight");
+        const bf16 *fw0 = W(c, f + "0.weight"), *fb0 = W(c, f + "0.bias");
+        const bf16 *fw1 = W(c, f + "1.weight"), *fb1 = W(c, f + "1.bias");
+        const bf16 *fw3 = W(c, f + "3.weight"), *fb3 = W(c, f + "3.bias");
+        if (!nmw || !nmb || !nlw || !nlb || !wq || !wkv || !wo || !fw0 || !fb0 || !fw1 || !fb1 || !fw3 || !fb3) return CR_ERR_STATE;
+
+        // kv_input = cat(norm_media(x), norm_learns(learns))      (:29-30,38)
+        CR_TRY(ln(x, kv_in, nmw, nmb, (int64_t)T * 256, 256, NKV, 0, st));
+        CR_TRY(ln(learns, kv_in, nlw, nlb, R, NQ, NKV, 256, st));
+        CR_TRY(ln(learns, lnl, nlw, nlb, R, 0, 0, 0, st));
+        CR_TRY(gemm(EPI_STORE, lnl, D, wq, D, q, INNER, nullptr, nullptr, 0, (int)R, INNER, D, st));              // :35
+        CR_TRY(gemm(EPI_STORE, kv_in, D, wkv, D, kv, 2 * INNER, nullptr, nullptr, 0, T * NKV, 2 * INNER, D, st));  // :39
+        hipLaunchKernelGGL(perceiver_attn_kernel, dim3(T, HEADS), dim3(64), 0, st, q, kv, ao, 0.125f);
+        CR_TRY(gemm(EPI_RES, ao, INNER, wo, INNER, learns, D, nullptr, learns, D, (int)R, D, INNER, st));          // :51 + :97
+        CR_TRY(ln(learns, lnl, fw0, fb0, R, 0, 0, 0, st));                                                         // FeedForward :134
+        CR_TRY(gemm(EPI_GELU, lnl, D, fw1, D, ff, 4 * D, fb1, nullptr, 0, (int)R, 4 * D, D, st));
+        CR_TRY(gemm(EPI_RES, ff, 4 * D, fw3, 4 * D, learns, D, fb3, learns, D, (int)R, D, 4 * D, st));             // :98
+    }
+    const bf16 *nw = W(c, "resampler.norm.weight"), *nb = W(c, "resampler.norm.bias");
+    if (!nw || !nb) return CR_ERR_STATE;
+    CR_TRY(ln(learns, (bf16*)out, nw, nb, R, 0, 0, 0, st));                                                        // :100
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int cr_vq(cr_ctx* c, const void* in, int n, int64_t* idx, void* cosv, void* stream) {
+    if (!c || !in || !idx || n <= 0) return cr_fail(CR_ERR_ARG, "cr_vq: bad argument");
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_vq: call cr_finalize first");
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const DevTensor* tb = WT(c, "derived.vq_table");
+    if (!tb) return CR_ERR_STATE;
+    const int V = (int)tb->shape[0];
+    const int64_t ld = (V + 7) & ~7;
+    CR_TRY(ws_ensure(c, ((size_t)n * D + (size_t)n * ld) * 2 + 4096));
+    Arena ar(c->ws);
+    bf16* xn = ar.take<bf16>((size_t)n * D);
+    bf16* sim = ar.take<bf16>((size_t)n * ld);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(n), dim3(256), 0, st, (const bf16*)in, xn, (int64_t)n);
+    CR_TRY(gemm(EPI_STORE, xn, D, (const bf16*)tb->ptr, D, sim, ld, nullptr, nullptr, 0, n, V, D, st));
+    hipLaunchKernelGGL(row_argmax_bf16_kernel, dim3(n), dim3(256), 0, st, sim, ld, V, idx, (bf16*)cosv);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int cr_denorm(cr_ctx* c, const void* in, const int64_t* idx, const void* cosv, int n, int flags, void* out,
+              int32_t* n_out, void* stream) {
+    if (!c || !in || !idx || !out || !n_out || n <= 0) return cr_fail(CR_ERR_ARG, "cr_denorm: bad argument");
+    if ((flags & 2) && !cosv) return cr_fail(CR_ERR_ARG, "cr_denorm: hard_vq needs the cosine values");
+    if ((size_t)n * 4 > c->scratch_bytes) return cr_fail(CR_ERR_ARG, "cr_denorm: n too large");
+    CR_HIP(hipSetDevice(c->device));
+    const DevTensor *mu = WT(c, "calli.mu"), *sg = WT(c, "calli.sigma"), *tb = WT(c, "normed_emb.weight");
+    if (!mu || !sg || !tb) return CR_ERR_STATE;
+    if (mu->dtype != sg->dtype) return cr_fail(CR_ERR_ARG, "calli.mu / calli.sigma dtypes differ");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* dst_row = (int32_t*)c->scratch;
+    hipLaunchKernelGGL(denorm_index_kernel, dim3(1), dim3(64), 0, st, idx, n, flags, n_out, dst_row);
+    if (mu->dtype == CR_F32)
+        hipLaunchKernelGGL(denorm_kernel<true>, dim3(n), dim3(256), 0, st, (const bf16*)in, idx, (const bf16*)cosv,
+                           (const bf16*)tb->ptr, mu->ptr, sg->ptr, flags, (bf16*)out, dst_row);
+    else
+        hipLaunchKernelGGL(denorm_kernel<false>, dim3(n), dim3(256), 0, st, (const bf16*)in, idx, (const bf16*)cosv,
+                           (const bf16*)tb->ptr, mu->ptr, sg->ptr, flags, (bf16*)out, dst_row);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+}  // extern "C"

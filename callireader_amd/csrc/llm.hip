@@ -1,0 +1,442 @@
+// Language-model stage: InternLM2.5-7B prefill + batched greedy decode over a pre-allocated KV cache.
+//   reference: InternVL/modeling_internlm2.py:129-143 (RMSNorm), :233-247 (RoPE), :250-264 (SwiGLU),
+//              :341-426 (attention), :621-681 (layer), :854-984 (model), :1022-1110 (LM head),
+//              :1112-1149 (prepare_inputs_for_generation); greedy loop = transformers 4.45.2 _sample.
+//
+// Per layer: RMSNorm -> GEMM wqkv -> RoPE + split (q to a dense buffer, k/v straight into the cache)
+//            -> flash attention (causal GQA in prefill; 4 heads of a KV group as the "rows" in decode)
+//            -> GEMM wo (+x in place) -> RMSNorm -> GEMM w1|w3 with SwiGLU epilogue -> GEMM w2 (+x in place).
+#include <vector>
+
+#include "attention.hpp"
+#include "ctx.hpp"
+#include "misc.hpp"
+#include "norm.hpp"
+
+struct cr_kv {
+    cr_ctx* ctx;
+    int n_seqs, max_tokens, gen_cap, layers;
+    bf16* k;             // [layers][n_seqs][8][max_tokens][128]
+    bf16* v;
+    int32_t* d_len;      // [n_seqs] tokens cached
+    int32_t* d_ngen;     // [n_seqs] ids generated
+    int64_t* d_gen;      // [n_seqs][gen_cap]
+    int32_t* d_seqs;     // [n_seqs] staging for the seqs[] of one decode call
+    std::vector<int> len, ngen;
+};
+
+namespace {
+
+constexpr int D = 4096, HD = 128, NH = 32, NKV = 8, QKV = 6144;
+
+// x[i] = tok_embeddings[id_i]; id_i = force[i] or the last generated id of seq_i
+__global__ __launch_bounds__(256) void embed_rows_kernel(const bf16* __restrict__ table, const int64_t* __restrict__ force,
+                                                         const int32_t* __restrict__ seqs, const int64_t* __restrict__ gen,
+                                                         const int32_t* __restrict__ ngen, int gen_cap, bf16* __restrict__ x) {
+    const int i = blockIdx.x;
+    int64_t id;
+    if (force) id = force[i];
+    else { const int s = seqs[i]; id = gen[(int64_t)s * gen_cap + ngen[s] - 1]; }
+    const bf16x8* src = (const bf16x8*)(table + id * D);
+    bf16x8* dst = (bf16x8*)(x + (int64_t)i * D);
+    dst[threadIdx.x] = src[threadIdx.x];
+    dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+}
+
+// splice: src_row[s] >= 0 -> table row; -1-r -> vit row r; -(1<<30)-r -> ref row r
+__global__ __launch_bounds__(1024) void splice_index_kernel(const int64_t* __restrict__ ids, int S, int64_t img_id, int64_t ref_id,
+                                                            int has_vit, int has_ref, int32_t* __restrict__ src_row,
+                                                            int32_t* __restrict__ counts) {
+    // one workgroup; running counts carried across chunks of 1024 ids
+    __shared__ int s_img[1024], s_ref[1024];
+    __shared__ int base_img, base_ref;
+    const int tid = threadIdx.x;
+    if (tid == 0) { base_img = 0; base_ref = 0; }
+    __syncthreads();
+    for (int s0 = 0; s0 < S; s0 += 1024) {
+        const int s = s0 + tid;
+        const int64_t id = s < S ? ids[s] : -1;
+        const int is_img = (has_vit && id == img_id) ? 1 : 0;
+        const int is_ref = (has_vit && has_ref && id == ref_id) ? 1 : 0;
+        s_img[tid] = is_img; s_ref[tid] = is_ref;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int a = tid >= o ? s_img[tid - o] : 0, b = tid >= o ? s_ref[tid - o] : 0;
+            __syncthreads();
+            s_img[tid] += a; s_ref[tid] += b;
+            __syncthreads();
+        }
+        if (s < S) {
+            int v = (int)id;
+            if (is_img) v = -1 - (base_img + s_img[tid] - 1);
+            else if (is_ref) v = -(1 << 30) - (base_ref + s_ref[tid] - 1);
+            src_row[s] = v;
+        }
+        __syncthreads();
+        if (tid == 1023) { base_img += s_img[1023]; base_ref += s_ref[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { counts[0] = base_img; counts[1] = base_ref; }
+}
+
+__global__ __launch_bounds__(256) void splice_rows_kernel(const bf16* __restrict__ table, const bf16* __restrict__ vit,
+                                                          const bf16* __restrict__ ref, const int32_t* __restrict__ src_row,
+                                                          int n_vit, int n_ref, bf16* __restrict__ out) {
+    const int s = blockIdx.x;
+    const int v = src_row[s];
+    const bf16* src;
+    if (v >= 0) src = table + (int64_t)v * D;
+    else if (v > -(1 << 30)) { const int r = -1 - v; if (r >= n_vit) return; src = vit + (int64_t)r * D; }
+    else { const int r = -(1 << 30) - v; if (r >= n_ref) return; src = ref + (int64_t)r * D; }
+    const bf16x8* sp = (const bf16x8*)src;
+    bf16x8* dp = (bf16x8*)(out + (int64_t)s * D);
+    dp[threadIdx.x] = sp[threadIdx.x];
+    dp[threadIdx.x + 256] = sp[threadIdx.x + 256];
+}
+
+// RoPE + split of the fused wqkv output (modeling_internlm2.py:359-388, 233-247).
+// qkv row = [8 groups][4 q | k | v][128].  q_embed = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), same for k.
+// grid (rows, 8 groups), 128 threads: thread = (slot 0..7 [6 used], 16-B chunk 0..15).
+__global__ __launch_bounds__(128) void rope_split_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ cosT,
+                                                         const bf16* __restrict__ sinT, bf16* __restrict__ q_out,
+                                                         bf16* __restrict__ kc, bf16* __restrict__ vc, int pos0, int seq0,
+                                                         const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
+                                                         int max_tokens) {
+    const int row = blockIdx.x, grp = blockIdx.y;
+    const int slot = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (slot >= 6) return;
+    const int seq = seqs ? seqs[row] : seq0;
+    const int pos = lens ? lens[seq] : pos0 + row;
+    const bf16* src = qkv + (int64_t)row * QKV + (grp * 6 + slot) * HD;
+    const bf16x8 x = *(const bf16x8*)(src + c * 8);
+    bf16x8 y;
+    if (slot < 5) {
+        const bf16x8 xp = *(const bf16x8*)(src + ((c + 8) & 15) * 8);
+        const bf16x8 cs = *(const bf16x8*)(cosT + (int64_t)pos * HD + c * 8);
+        const bf16x8 sn = *(const bf16x8*)(sinT + (int64_t)pos * HD + c * 8);
+        const float sign = c < 8 ? -1.0f : 1.0f;           // rotate_half: (-x2, x1)
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            y[e] = f2bf(rbf(bf2f(x[e]) * bf2f(cs[e])) + rbf(sign * bf2f(xp[e]) * bf2f(sn[e])));
+    } else {
+        y = x;
+    }
+    bf16* dst;
+    if (slot < 4) dst = q_out + (int64_t)row * D + (grp * 4 + slot) * HD;
+    else {
+        bf16* base = slot == 4 ? kc : vc;
+        dst = base + (((int64_t)seq * NKV + grp) * max_tokens + pos) * HD;
+    }
+    *(bf16x8*)(dst + c * 8) = y;
+}
+
+// RepetitionPenaltyLogitsProcessor (published 4.45.2 semantics) + argmax (first max wins) + append the id.
+// One workgroup of 1024 per row.
+__global__ __launch_bounds__(1024) void pick_kernel(float* __restrict__ logits, int64_t ld, int vocab, float penalty,
+                                                    int seq0, const int32_t* __restrict__ seqs, int64_t* __restrict__ gen,
+                                                    int32_t* __restrict__ ngen, int32_t* __restrict__ lens, int gen_cap, int len_add) {
+    __shared__ float bv[1024];
+    __shared__ int bi[1024];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int seq = seqs ? seqs[row] : seq0;
+    float* lg = logits + (int64_t)row * ld;
+    const int ng = ngen[seq];
+    int64_t* g = gen + (int64_t)seq * gen_cap;
+    if (penalty != 1.0f && ng > 0) {
+        // gather every score first, then scatter: duplicates of an id all see the ORIGINAL score
+        float sv[4]; int64_t si[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int h = tid + k * 1024;
+            si[k] = h < ng ? g[h] : -1;
+            sv[k] = si[k] >= 0 ? lg[si[k]] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (si[k] >= 0) lg[si[k]] = sv[k] < 0.f ? sv[k] * penalty : sv[k] / penalty;
+        __syncthreads();
+    }
+    float best = -INFINITY; int besti = 0x7fffffff;
+    for (int c = tid; c < vocab; c += 1024) {
+        const float v = lg[c];
+        if (v > best) { best = v; besti = c; }
+    }
+    bv[tid] = best; bi[tid] = besti;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v2 = bv[tid + o]; const int i2 = bi[tid + o];
+            if (v2 > bv[tid] || (v2 == bv[tid] && i2 < bi[tid])) { bv[tid] = v2; bi[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (ng < gen_cap) { g[ng] = bi[0]; ngen[seq] = ng + 1; }
+        lens[seq] += len_add;
+    }
+}
+
+// w13 rows: [16q + e] = w1[8q + e], [16q + 8 + e] = w3[8q + e]   (pairs gate/up for the SwiGLU epilogue)
+__global__ __launch_bounds__(256) void interleave8_kernel(const bf16* __restrict__ w1, const bf16* __restrict__ w3,
+                                                          bf16* __restrict__ out, int ff) {
+    const int r = blockIdx.x;                 // output row, 0 .. 2*ff
+    const int q = r >> 4, e = r & 15;
+    const bf16* src = (e < 8 ? w1 : w3) + (int64_t)(q * 8 + (e & 7)) * D;
+    const bf16x8* sp = (const bf16x8*)src;
+    bf16x8* dp = (bf16x8*)(out + (int64_t)r * D);
+    dp[threadIdx.x] = sp[threadIdx.x];
+    dp[threadIdx.x + 256] = sp[threadIdx.x + 256];
+}
+
+int gemm(int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
+         int M, int N, int K, hipStream_t st) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.res = res; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
+    int r = launch_gemm(epi, p, st);
+    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) failed", epi, M, N, K);
+    return CR_OK;
+}
+
+int rms(const bf16* in, int64_t ld_in, bf16* out, const bf16* w, int64_t rows, float eps, hipStream_t st) {
+    NormParams np{};
+    np.in = in; np.ld_in = ld_in; np.out = out; np.ld_out = D; np.gamma = w; np.rows = rows; np.eps = eps;
+    return launch_rmsnorm(np, D, st);
+}
+
+struct LayerW { const bf16 *an, *fn, *wqkv, *wo, *w13, *w2; };
+
+int layer_weights(cr_ctx* c, int l, LayerW& w) {
+    const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
+    w.an = W(c, p + "attention_norm.weight"); w.fn = W(c, p + "ffn_norm.weight");
+    w.wqkv = W(c, p + "attention.wqkv.weight"); w.wo = W(c, p + "attention.wo.weight");
+    w.w13 = W(c, "derived.w13." + std::to_string(l)); w.w2 = W(c, p + "feed_forward.w2.weight");
+    return (w.an && w.fn && w.wqkv && w.wo && w.w13 && w.w2) ? CR_OK : CR_ERR_STATE;
+}
+
+// The decoder stack over M rows (prefill: M = S rows of one sequence; decode: M = n sequences, one row each).
+int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int pos0, const int32_t* d_seqs, hipStream_t st) {
+    const int ff = (int)WT(c, "derived.w13.0")->shape[0] / 2;
+    Arena ar(c->ws);
+    bf16* h = ar.take<bf16>((size_t)M * D);
+    bf16* qkv = ar.take<bf16>((size_t)M * QKV);
+    bf16* q = ar.take<bf16>((size_t)M * D);
+    bf16* ao = ar.take<bf16>((size_t)M * D);
+    bf16* act = ar.take<bf16>((size_t)M * ff);
+    const bf16 *cosT = W(c, "rope.cos"), *sinT = W(c, "rope.sin");
+    if (!cosT || !sinT) return CR_ERR_STATE;
+    const int64_t per_layer = (int64_t)kv->n_seqs * NKV * kv->max_tokens * HD;
+    for (int l = 0; l < c->d.llm_layers; l++) {
+        LayerW w;
+        CR_TRY(layer_weights(c, l, w));
+        bf16* kc = kv->k + l * per_layer;
+        bf16* vc = kv->v + l * per_layer;
+        CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
+        CR_TRY(gemm(EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
+        hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, pos0, seq0,
+                           decode ? d_seqs : nullptr, decode ? kv->d_len : nullptr, kv->max_tokens);
+        AttnParams ap{};
+        ap.K = kc; ap.V = vc; ap.Q = q; ap.O = ao;
+        ap.k_bs = ap.v_bs = (int64_t)NKV * kv->max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)kv->max_tokens * HD;
+        ap.q_prescale = 1.0f; ap.s_div = 11.313708498984761f;      // math.sqrt(128)
+        if (!decode) {
+            ap.q_bs = 0; ap.q_rs = D; ap.q_hs = HD; ap.o_bs = 0; ap.o_rs = D; ap.o_hs = HD;
+            ap.B = 1; ap.H = NH; ap.Sq = M; ap.Sk = pos0 + M; ap.kv_group = NH / NKV; ap.q_pos0 = pos0;
+            ap.K = kc + (int64_t)seq0 * ap.k_bs; ap.V = vc + (int64_t)seq0 * ap.v_bs;
+            if (launch_flash_attn(ap, HD, true, st) != CR_OK) return cr_fail(CR_ERR_HIP, "prefill attention launch failed");
+        } else {
+            // rows = the 4 query heads of one KV group, all at the same position: no mask needed
+            ap.q_bs = D; ap.q_rs = HD; ap.q_hs = 4 * HD; ap.o_bs = D; ap.o_rs = HD; ap.o_hs = 4 * HD;
+            ap.B = M; ap.H = NKV; ap.Sq = NH / NKV; ap.Sk = 0; ap.kv_group = 1; ap.q_pos0 = 0;
+            ap.seq_map = d_seqs; ap.sk_arr = kv->d_len; ap.sk_add = 1;
+            if (launch_flash_attn(ap, HD, false, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
+        }
+        CR_TRY(gemm(EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+        CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
+        CR_TRY(gemm(EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
+        CR_TRY(gemm(EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
+    }
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+size_t layers_ws(cr_ctx* c, int M) {
+    const size_t ff = (size_t)WT(c, "derived.w13.0")->shape[0] / 2;
+    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + 8192;
+}
+
+}  // namespace
+
+int llm_finalize(cr_ctx* c, hipStream_t st) {
+    for (int l = 0; l < c->d.llm_layers; l++) {
+        const std::string p = "language_model.model.layers." + std::to_string(l) + ".feed_forward.";
+        auto i1 = c->w.find(p + "w1.weight"), i3 = c->w.find(p + "w3.weight");
+        const std::string dn = "derived.w13." + std::to_string(l);
+        if (i1 == c->w.end() || i3 == c->w.end()) {
+            if (c->w.count(dn)) continue;          // already derived, originals released
+            return cr_fail(CR_ERR_STATE, "layer %d: w1/w3 missing", l);
+        }
+        const int ff = (int)i1->second.shape[0];
+        if (i1->second.shape[1] != D || i3->second.shape != i1->second.shape || (ff % 8))
+            return cr_fail(CR_ERR_ARG, "layer %d: w1/w3 must be [ff,4096] with ff %% 8 == 0", l);
+        DevTensor t;
+        t.dtype = CR_BF16; t.shape = {2 * ff, D}; t.bytes = (size_t)2 * ff * D * 2;
+        auto old = c->w.find(dn);
+        if (old != c->w.end()) { hipFree(old->second.ptr); c->w.erase(old); }
+        CR_HIP(hipMalloc(&t.ptr, t.bytes));
+        hipLaunchKernelGGL(interleave8_kernel, dim3(2 * ff), dim3(256), 0, st, (const bf16*)i1->second.ptr,
+                           (const bf16*)i3->second.ptr, (bf16*)t.ptr, ff);
+        CR_HIP(hipStreamSynchronize(st));
+        hipFree(i1->second.ptr); hipFree(i3->second.ptr);      // the interleaved copy replaces them
+        c->w.erase(i1); c->w.erase(c->w.find(p + "w3.weight"));
+        c->w[dn] = t;
+    }
+    return CR_OK;
+}
+
+extern "C" {
+
+int cr_embed_splice(cr_ctx* c, const int64_t* ids, int S, const void* vit, int n_vit, int64_t img_id, const void* ref,
+                    int n_ref, int64_t ref_id, void* out, void* stream) {
+    if (!c || !ids || !out || S <= 0) return cr_fail(CR_ERR_ARG, "cr_embed_splice: bad argument");
+    if ((size_t)S * 4 + 64 > c->scratch_bytes) return cr_fail(CR_ERR_ARG, "cr_embed_splice: S too large");
+    CR_HIP(hipSetDevice(c->device));
+    const bf16* table = W(c, "language_model.model.tok_embeddings.weight");
+    if (!table) return CR_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* counts = (int32_t*)c->scratch;
+    int32_t* src_row = counts + 16;
+    hipLaunchKernelGGL(splice_index_kernel, dim3(1), dim3(1024), 0, st, ids, S, img_id, ref_id, vit ? 1 : 0, ref ? 1 : 0, src_row, counts);
+    hipLaunchKernelGGL(splice_rows_kernel, dim3(S), dim3(256), 0, st, table, (const bf16*)vit, (const bf16*)ref, src_row, n_vit, n_ref, (bf16*)out);
+    CR_HIP(hipGetLastError());
+    // `input_embeds[selected] = vit_embeds` raises on a count mismatch in the reference; check it the same way
+    int32_t hc[2];
+    CR_HIP(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, st));
+    CR_HIP(hipStreamSynchronize(st));
+    if (vit && hc[0] != n_vit) return cr_fail(CR_ERR_ARG, "cr_embed_splice: %d <IMG_CONTEXT> ids but %d visual rows", hc[0], n_vit);
+    if (vit && hc[0] == 0) return cr_fail(CR_ERR_ARG, "cr_embed_splice: no <IMG_CONTEXT> id in the prompt");
+    if (vit && ref && hc[1] != n_ref) return cr_fail(CR_ERR_ARG, "cr_embed_splice: %d pseudo-token ids but %d rows", hc[1], n_ref);
+    if (vit && ref && hc[1] == 0) return cr_fail(CR_ERR_ARG, "cr_embed_splice: no pseudo-token id in the prompt");
+    return CR_OK;
+}
+
+int cr_kv_alloc(cr_ctx* c, int n_seqs, int max_tokens, cr_kv** out) {
+    if (!c || !out || n_seqs <= 0 || max_tokens <= 0) return cr_fail(CR_ERR_ARG, "cr_kv_alloc: bad argument");
+    if (max_tokens > c->d.max_pos) return cr_fail(CR_ERR_ARG, "cr_kv_alloc: max_tokens %d exceeds the RoPE table (%d rows)", max_tokens, c->d.max_pos);
+    CR_HIP(hipSetDevice(c->device));
+    cr_kv* kv = new cr_kv();
+    kv->ctx = c; kv->n_seqs = n_seqs; kv->max_tokens = max_tokens; kv->gen_cap = 4096; kv->layers = c->d.llm_layers;
+    const size_t bytes = (size_t)kv->layers * n_seqs * NKV * max_tokens * HD * 2;
+    if (hipMalloc((void**)&kv->k, bytes) != hipSuccess || hipMalloc((void**)&kv->v, bytes) != hipSuccess ||
+        hipMalloc((void**)&kv->d_len, n_seqs * 4) != hipSuccess || hipMalloc((void**)&kv->d_ngen, n_seqs * 4) != hipSuccess ||
+        hipMalloc((void**)&kv->d_seqs, n_seqs * 4) != hipSuccess ||
+        hipMalloc((void**)&kv->d_gen, (size_t)n_seqs * kv->gen_cap * 8) != hipSuccess) {
+        cr_kv_free(kv);
+        return cr_fail(CR_ERR_NOMEM, "cr_kv_alloc: %zu bytes per K/V", bytes);
+    }
+    CR_HIP(hipMemset(kv->d_len, 0, n_seqs * 4));
+    CR_HIP(hipMemset(kv->d_ngen, 0, n_seqs * 4));
+    kv->len.assign(n_seqs, 0); kv->ngen.assign(n_seqs, 0);
+    *out = kv;
+    return CR_OK;
+}
+
+int cr_kv_free(cr_kv* kv) {
+    if (!kv) return CR_OK;
+    hipDeviceSynchronize();
+    if (kv->k) hipFree(kv->k);
+    if (kv->v) hipFree(kv->v);
+    if (kv->d_len) hipFree(kv->d_len);
+    if (kv->d_ngen) hipFree(kv->d_ngen);
+    if (kv->d_seqs) hipFree(kv->d_seqs);
+    if (kv->d_gen) hipFree(kv->d_gen);
+    delete kv;
+    return CR_OK;
+}
+
+int cr_kv_length(const cr_kv* kv, int seq) { return (kv && seq >= 0 && seq < kv->n_seqs) ? kv->len[seq] : -1; }
+
+int cr_kv_reset(cr_kv* kv, int seq) {
+    if (!kv || seq < 0 || seq >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_kv_reset: bad sequence");
+    CR_HIP(hipDeviceSynchronize());
+    CR_HIP(hipMemset(kv->d_len + seq, 0, 4));
+    CR_HIP(hipMemset(kv->d_ngen + seq, 0, 4));
+    kv->len[seq] = 0; kv->ngen[seq] = 0;
+    return CR_OK;
+}
+
+int cr_kv_generated(cr_kv* kv, int seq, int64_t* out_host, int max, void* stream) {
+    if (!kv || !out_host || seq < 0 || seq >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_kv_generated: bad argument");
+    const int n = kv->ngen[seq] < max ? kv->ngen[seq] : max;
+    if (n > 0) CR_HIP(hipMemcpyAsync(out_host, kv->d_gen + (size_t)seq * kv->gen_cap, (size_t)n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return n;
+}
+
+int cr_llm_prefill(cr_ctx* c, cr_kv* kv, int seq, const void* embeds, int S, float penalty, float* last_logits, void* stream) {
+    if (!c || !kv || !embeds || S <= 0 || seq < 0 || seq >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_prefill: bad argument");
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_llm_prefill: call cr_finalize first");
+    if (kv->len[seq] + S > kv->max_tokens) return cr_fail(CR_ERR_ARG, "cr_llm_prefill: %d + %d tokens exceed the cache (%d)", kv->len[seq], S, kv->max_tokens);
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = c->d.vocab;
+    const size_t lw = layers_ws(c, S);
+    CR_TRY(ws_ensure(c, lw + (size_t)S * D * 2 + (size_t)D * 2 + (size_t)V * 4 + 4096));
+    bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
+    bf16* hl = x + (size_t)S * D;
+    float* lg = (float*)(((uintptr_t)(hl + D) + 255) & ~(uintptr_t)255);
+    CR_HIP(hipMemcpyAsync(x, embeds, (size_t)S * D * 2, hipMemcpyDeviceToDevice, st));
+    CR_TRY(run_layers(c, kv, x, S, false, seq, kv->len[seq], nullptr, st));
+    const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
+    if (!nw || !ow) return CR_ERR_STATE;
+    // only the last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)
+    CR_TRY(rms(x + (size_t)(S - 1) * D, D, hl, nw, 1, c->d.rms_eps, st));
+    CR_TRY(gemm(EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, 1, V, D, st));
+    if (last_logits) CR_HIP(hipMemcpyAsync(last_logits, lg, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, seq, (const int32_t*)nullptr,
+                       kv->d_gen, kv->d_ngen, kv->d_len, kv->gen_cap, S);
+    CR_HIP(hipGetLastError());
+    kv->len[seq] += S;
+    if (kv->ngen[seq] < kv->gen_cap) kv->ngen[seq] += 1;
+    return CR_OK;
+}
+
+int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_t* force_tokens, float penalty, float* logits,
+                  void* stream) {
+    if (!c || !kv || !seqs || n <= 0 || n > kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_decode: bad argument");
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_llm_decode: call cr_finalize first");
+    for (int i = 0; i < n; i++) {
+        const int s = seqs[i];
+        if (s < 0 || s >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_decode: sequence %d out of range", s);
+        if (kv->len[s] + 1 > kv->max_tokens) return cr_fail(CR_ERR_ARG, "cr_llm_decode: sequence %d cache full", s);
+        if (!force_tokens && kv->ngen[s] == 0) return cr_fail(CR_ERR_STATE, "cr_llm_decode: sequence %d has no generated id to feed", s);
+        for (int j = 0; j < i; j++) if (seqs[j] == s) return cr_fail(CR_ERR_ARG, "cr_llm_decode: sequence %d listed twice", s);
+    }
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = c->d.vocab;
+    const size_t lw = layers_ws(c, n);
+    CR_TRY(ws_ensure(c, lw + (size_t)n * D * 4 + (size_t)n * V * 4 + 4096));
+    bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
+    bf16* hl = x + (size_t)n * D;
+    float* lg = (float*)(((uintptr_t)(hl + (size_t)n * D) + 255) & ~(uintptr_t)255);
+    CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    const bf16* table = W(c, "language_model.model.tok_embeddings.weight");
+    const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
+    if (!table || !nw || !ow) return CR_ERR_STATE;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, table, force_tokens, kv->d_seqs, kv->d_gen, kv->d_ngen, kv->gen_cap, x);
+    CR_TRY(run_layers(c, kv, x, n, true, 0, 0, kv->d_seqs, st));
+    CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
+    CR_TRY(gemm(EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
+    if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(pick_kernel, dim3(n), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, 0, kv->d_seqs, kv->d_gen, kv->d_ngen,
+                       kv->d_len, kv->gen_cap, 1);
+    CR_HIP(hipGetLastError());
+    for (int i = 0; i < n; i++) {
+        kv->len[seqs[i]] += 1;
+        if (kv->ngen[seqs[i]] < kv->gen_cap) kv->ngen[seqs[i]] += 1;
+    }
+    return CR_OK;
+}
+
+}  // extern "C"

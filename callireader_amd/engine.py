@@ -156,29 +156,20 @@ class Engine:
         B.check(B.lib.cr_kv_alloc(self._h, n_seqs, max_tokens, C.byref(h)), 'cr_kv_alloc')
         return KVCache(self, h, n_seqs, max_tokens)
 
-    def prefill(self, kv, seq, embeds, want_logits=False):
+    def prefill(self, kv, seq, embeds, penalty=1.0, want_logits=False):
         e = embeds.reshape(-1, self.dims.llm_hidden).contiguous()
         S = e.shape[0]
         logits = torch.empty(self.dims.vocab, device=self.device, dtype=torch.float32) if want_logits else None
-        nxt = torch.empty(1, device=self.device, dtype=torch.int64)
-        B.check(B.lib.cr_llm_prefill(self._h, kv._h, seq, _p(e), S, _p(logits), _p(nxt), _stream()), 'cr_llm_prefill')
-        return (nxt, logits) if want_logits else nxt
+        B.check(B.lib.cr_llm_prefill(self._h, kv._h, seq, _p(e), S, float(penalty), _p(logits), _stream()), 'cr_llm_prefill')
+        return logits
 
-    def decode(self, kv, seqs, tokens, penalty=1.0, history=None, hist_len=None, want_logits=False):
+    def decode(self, kv, seqs, penalty=1.0, force_tokens=None, want_logits=False):
         n = len(seqs)
         seq_arr = (C.c_int32 * n)(*seqs)
-        tokens = tokens.reshape(-1).to(self.device, torch.int64).contiguous()
+        ft = force_tokens.reshape(-1).to(self.device, torch.int64).contiguous() if force_tokens is not None else None
         logits = torch.empty(n, self.dims.vocab, device=self.device, dtype=torch.float32) if want_logits else None
-        nxt = torch.empty(n, device=self.device, dtype=torch.int64)
-        if history is not None:
-            hl = (C.c_int32 * n)(*hist_len)
-            stride = history.shape[1]
-        else:
-            hl = (C.c_int32 * n)(*([0] * n))
-            stride = 0
-        B.check(B.lib.cr_llm_decode(self._h, kv._h, seq_arr, n, _p(tokens), _p(logits), float(penalty),
-                                    _p(history), stride, hl, _p(nxt), _stream()), 'cr_llm_decode')
-        return (nxt, logits) if want_logits else nxt
+        B.check(B.lib.cr_llm_decode(self._h, kv._h, seq_arr, n, _p(ft), float(penalty), _p(logits), _stream()), 'cr_llm_decode')
+        return logits
 
 
 class KVCache:
@@ -190,6 +181,13 @@ class KVCache:
 
     def reset(self, seq):
         B.check(B.lib.cr_kv_reset(self._h, seq), 'cr_kv_reset')
+
+    def generated(self, seq, max_tokens=4096):
+        buf = (C.c_int64 * max_tokens)()
+        n = B.lib.cr_kv_generated(self._h, seq, buf, max_tokens, _stream())
+        if n < 0:
+            B.check(n, 'cr_kv_generated')
+        return list(buf[:n])
 
     def free(self):
         if self._h:

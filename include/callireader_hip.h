@@ -91,25 +91,31 @@ int cr_embed_splice(cr_ctx* ctx, const int64_t* ids, int S, const void* vit_embe
                     const void* ref_embeds, int n_ref, int64_t ref_id, void* out, void* stream);
 
 /* KV cache for `n_seqs` sequences of up to `max_tokens` tokens: replaces the reference's tuple cache grown by
- * torch.cat (InternVL/modeling_internlm2.py:383-388). */
+ * torch.cat (InternVL/modeling_internlm2.py:383-388).  The object also keeps, per sequence, the ids generated so
+ * far — what transformers' generate() carries as `input_ids` when only inputs_embeds is given — so that the
+ * repetition penalty and the next step's input never leave the device. */
 int cr_kv_alloc(cr_ctx* ctx, int n_seqs, int max_tokens, cr_kv** out);
 int cr_kv_free(cr_kv* kv);
-int cr_kv_length(const cr_kv* kv, int seq);           /* tokens currently held (host-side bookkeeping) */
-int cr_kv_reset(cr_kv* kv, int seq);
+int cr_kv_length(const cr_kv* kv, int seq);           /* tokens currently cached (host-side bookkeeping) */
+int cr_kv_reset(cr_kv* kv, int seq);                  /* forget the sequence: length 0, no generated ids */
+/* Copy the ids generated so far for `seq` into host memory (at most `max`); returns the count, or < 0.
+ * Synchronises `stream`. */
+int cr_kv_generated(cr_kv* kv, int seq, int64_t* out_host, int max, void* stream);
 
-/* InternLM2ForCausalLM.forward(inputs_embeds=…, use_cache=True) — InternVL/modeling_internlm2.py:1022-1110,
- * for ONE sequence `seq` of the cache, appended at its current length.  embeds [S,4096].
- * last_logits [vocab] fp32 (may be NULL), next_token: device int64 = argmax of the last row (first max wins). */
-int cr_llm_prefill(cr_ctx* ctx, cr_kv* kv, int seq, const void* embeds, int S, float* last_logits,
-                   int64_t* next_token, void* stream);
-/* One greedy step for sequences seqs[0..n) (host int array): embeds tokens[i] (device int64), appends to the cache,
- * logits [n,vocab] fp32 (may be NULL), applies HF RepetitionPenaltyLogitsProcessor over `history`
- * (device int64 [n, hist_stride], hist_len[i] valid entries each, host array) when penalty != 1, writes
- * next_tokens[i] = argmax.  Replaces one iteration of transformers 4.45.2 GenerationMixin._sample as driven from
- * InternVL/modeling_internvl_chat.py:1111-1120. */
-int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int64_t* tokens, float* logits,
-                  float penalty, const int64_t* history, int hist_stride, const int32_t* hist_len,
-                  int64_t* next_tokens, void* stream);
+/* InternLM2ForCausalLM.forward(inputs_embeds=…, use_cache=True) — InternVL/modeling_internlm2.py:1022-1110 —
+ * for ONE sequence `seq`, appended at its current length; then the first greedy pick of
+ * transformers 4.45.2 GenerationMixin._sample (RepetitionPenaltyLogitsProcessor over the ids generated so far,
+ * argmax with first-max-wins), appended to the sequence's generated ids.
+ * embeds [S,4096]; last_logits [vocab] fp32 = raw last-row logits before the penalty (may be NULL). */
+int cr_llm_prefill(cr_ctx* ctx, cr_kv* kv, int seq, const void* embeds, int S, float penalty, float* last_logits,
+                   void* stream);
+/* One greedy step for sequences seqs[0..n) (host array): embed each sequence's last generated id (or
+ * force_tokens[i], device int64, when not NULL), run the decoder against the cache, append K/V, apply the
+ * penalty, argmax, append the new id.  logits [n,vocab] fp32 raw (may be NULL).  Replaces one iteration of
+ * GenerationMixin._sample as driven from InternVL/modeling_internvl_chat.py:1111-1120 with
+ * prepare_inputs_for_generation (InternVL/modeling_internlm2.py:1112-1149). */
+int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int64_t* force_tokens, float penalty,
+                  float* logits, void* stream);
 
 /* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
 /* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32 */

@@ -1,0 +1,101 @@
+"""CalliAlign parity on a real MI355X: resampler, cosine VQ, de-normalisation vs the CPU oracle."""
+import pytest
+import torch
+
+from callireader_amd.config import ModelDims
+from callireader_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from callireader_amd.engine import Engine
+    from oracle import calli_align
+    dims = ModelDims.reduced(vit_layers=1, llm_layers=1, rs_depth=2, vocab=5003)     # ragged vocab
+    sd = synthetic.make_state_dict(dims, parts=('resampler', 'vq'), seed=0)
+    eng = Engine(dims)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    g = torch.Generator().manual_seed(5)
+    feats = (torch.randn(5, 256, 4096, generator=g) * 0.7).to(torch.bfloat16)
+    with torch.no_grad():
+        rs = calli_align.resampler_forward(sd, feats, dims.rs_depth)
+    return dict(eng=eng, dims=dims, sd=sd, feats=feats, rs=rs, oracle=calli_align)
+
+
+def test_resampler(setup):
+    out = setup['eng'].resample(setup['feats'].cuda())
+    torch.cuda.synchronize()
+    got, ref = out.float().cpu(), setup['rs'].float()
+    assert got.shape == ref.shape == (5, 3, 4096)
+    assert rel_l2(got, ref) <= 1.5e-2
+    assert float((got - ref).abs().max()) <= 8e-2 * float(ref.abs().max())
+
+
+def test_resampler_single_tile(setup):
+    out = setup['eng'].resample(setup['feats'][:1].cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), setup['rs'][:1].float()) <= 1.5e-2
+
+
+def test_vq_planted_and_random(setup):
+    o, sd = setup['oracle'], setup['sd']
+    table = sd['normed_emb.weight']
+    q = setup['rs'].clone()
+    q[0, 0] = table[123] * 3.0
+    q[1, 2] = table[5002] * 0.5          # last row of a ragged table
+    q[2, 1] = table[0] * 2.0
+    ridx, rcos = o.vq_cos_sim(table, q, use_dynamic_p=True)
+    idx, cos = setup['eng'].vq(q.cuda(), with_cos=True)
+    torch.cuda.synchronize()
+    idx, cos = idx.cpu(), cos.float().cpu()
+    assert idx.shape == (5, 3) and idx.dtype == torch.int64
+    assert int(idx[0, 0]) == 123 and int(idx[1, 2]) == 5002 and int(idx[2, 1]) == 0
+    # cosine of the planted rows is ~1 on both sides; elsewhere the max cosine must agree to bf16 resolution
+    assert torch.allclose(cos, rcos.float(), atol=8e-3)
+    # random rows: near-ties between table rows are possible at bf16; accept an index whose cosine ties
+    # the oracle's maximum within one bf16 step of the similarity matrix
+    xn = torch.nn.functional.normalize(q, p=2, dim=2)
+    tn = torch.nn.functional.normalize(table, p=2, dim=1)
+    sim = torch.matmul(xn, tn.t()).float()
+    picked = sim.gather(2, idx.unsqueeze(-1)).squeeze(-1)
+    assert (sim.max(dim=2).values - picked <= 8e-3).all()
+    assert (idx == ridx).float().mean() >= 0.8
+
+
+def test_denorm_branches(setup):
+    o, sd, eng = setup['oracle'], setup['sd'], setup['eng']
+    table, mu, sigma = sd['normed_emb.weight'], sd['calli.mu'], sd['calli.sigma']
+    x = setup['rs']
+    idx = torch.tensor([[0, 3, 5], [7, 0, 2], [9, 9, 0], [1, 2, 3], [0, 0, 4]])
+    cos = torch.tensor([[0.9, 0.4, 0.5], [0.6, 0.1, 0.95], [0.7, 0.2, 0.3], [0.99, 0.5, 0.51], [0.0, 1.0, 0.49]]).bfloat16()
+    for drop_zero in (False, True):
+        for hard in (False, True):
+            ref, _ = o.denormalise(x, idx, table, mu, sigma, drop_zero=drop_zero, hard_vq=hard, cos=cos)
+            got = eng.denorm(x.cuda(), idx.cuda(), cos.cuda(), drop_zero=drop_zero, hard_vq=hard)
+            torch.cuda.synchronize()
+            assert got.shape == ref.shape
+            assert torch.equal(got.cpu(), ref), (drop_zero, hard)      # elementwise bf16 ops: bit-exact
+
+
+def test_denorm_fp32_params(setup):
+    from callireader_amd.engine import Engine
+    sd = dict(setup['sd'])
+    eng = Engine(setup['dims'])
+    eng.load_weight('normed_emb.weight', sd['normed_emb.weight'])
+    eng.load_weight('calli.mu', sd['calli.mu'].float())
+    eng.load_weight('calli.sigma', sd['calli.sigma'].float())
+    eng.finalize()
+    x = setup['rs']
+    idx = torch.randint(0, 5003, (5, 3))
+    got = eng.denorm(x.cuda(), idx.cuda())
+    torch.cuda.synchronize()
+    flat = x.reshape(-1, 4096)
+    ref = (flat * sd['calli.sigma'].float()[idx.reshape(-1)] + sd['calli.mu'].float()[idx.reshape(-1)]).to(torch.bfloat16)
+    assert torch.equal(got.cpu(), ref)

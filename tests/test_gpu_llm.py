@@ -1,0 +1,176 @@
+"""InternLM2 prefill + greedy decode parity on a real MI355X vs the CPU oracle (2 layers, full width).
+
+Logit tolerance ("fp16 logit tolerance" of BASELINE.json's north_star): the LM head is a bf16 GEMM whose output is
+rounded to bf16 then upcast (modeling_internlm2.py:1081-1082), so one logit ulp at |x|~2 is 2^-7 = 7.8e-3; two
+bf16-eager layers with a different accumulation order add a few ulp: |diff| <= 6e-2 and rel-L2 <= 2e-2.
+Token parity: greedy ids must match the oracle exactly, except where the oracle's own top-2 margin is inside that
+logit tolerance (a near-tie) — then the test continues teacher-forced and reports the position.
+"""
+import pytest
+import torch
+
+from callireader_amd.config import ModelDims
+from callireader_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+ATOL = 6e-2
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from callireader_amd.engine import Engine
+    dims = ModelDims.reduced(vit_layers=1, llm_layers=2, rs_depth=1, vocab=8201)      # ragged vocab like 92553
+    sd = synthetic.make_state_dict(dims, parts=('llm',), seed=0)
+    eng = Engine(dims, max_pos=2048)
+    eng.load_state_dict(sd)
+    eng.load_rope()
+    eng.finalize()
+    return dict(eng=eng, dims=dims, sd=sd)
+
+
+def prompt(S, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(1, S, 4096, generator=g) * 0.02).to(torch.bfloat16)
+
+
+def oracle_run(sd, emb, steps, penalty=1.0):
+    from oracle import generate
+    with torch.no_grad():
+        ids, logits = generate.greedy_generate(sd, 2, emb, max_new_tokens=steps, eos_token_id=-1,
+                                               repetition_penalty=penalty, return_logits=True)
+    return ids[0].tolist(), logits
+
+
+def check_stream(eng, kv, seq, emb, ref_ids, ref_logits, penalty=1.0):
+    """Teacher-forced walk along the oracle's ids; returns the list of positions where the greedy pick differed."""
+    lg = eng.prefill(kv, seq, emb.cuda(), penalty=penalty, want_logits=True)
+    torch.cuda.synchronize()
+    diverged = []
+    for t in range(len(ref_ids)):
+        got, ref = lg.float().cpu().reshape(-1), ref_logits[t]
+        assert rel_l2(got, ref) <= 2e-2, (t, rel_l2(got, ref))
+        assert float((got - ref).abs().max()) <= ATOL, (t, float((got - ref).abs().max()))
+        picked = kv.generated(seq)[t]
+        if picked != ref_ids[t]:
+            # only acceptable at a near-tie of the (penalised) oracle scores
+            from oracle.generate import apply_repetition_penalty
+            sc = apply_repetition_penalty(ref, ref_ids[:t], penalty)
+            assert float(sc[ref_ids[t]] - sc[picked]) <= 2 * ATOL, (t, picked, ref_ids[t])
+            diverged.append(t)
+        if t + 1 < len(ref_ids):
+            lg = eng.decode(kv, [seq], penalty=penalty, force_tokens=torch.tensor([ref_ids[t]]), want_logits=True)
+            torch.cuda.synchronize()
+    return diverged
+
+
+@pytest.mark.parametrize('S', [300, 17, 129])
+def test_prefill_and_teacher_forced_decode(setup, S):
+    eng, sd = setup['eng'], setup['sd']
+    emb = prompt(S, 100 + S)
+    ref_ids, ref_logits = oracle_run(sd, emb, 6)
+    kv = eng.kv_alloc(1, 512)
+    div = check_stream(eng, kv, 0, emb, ref_ids, ref_logits)
+    assert kv.length(0) == S + 5
+    assert len(div) <= 1, f'greedy ids diverged from the oracle at steps {div}'
+    kv.free()
+
+
+def test_free_running_greedy_tokens(setup):
+    eng, sd = setup['eng'], setup['sd']
+    emb = prompt(200, 7)
+    ref_ids, ref_logits = oracle_run(sd, emb, 12)
+    kv = eng.kv_alloc(1, 512)
+    eng.prefill(kv, 0, emb.cuda())
+    for _ in range(11):
+        eng.decode(kv, [0])
+    got = kv.generated(0)
+    assert len(got) == 12
+    first_div = next((i for i, (a, b) in enumerate(zip(got, ref_ids)) if a != b), None)
+    if first_div is not None:
+        top2 = torch.topk(ref_logits[first_div], 2).values
+        assert float(top2[0] - top2[1]) <= 2 * ATOL, f'diverged at {first_div} without a near-tie'
+    else:
+        assert got == ref_ids
+    kv.free()
+
+
+def test_repetition_penalty(setup):
+    eng, sd = setup['eng'], setup['sd']
+    emb = prompt(64, 11)
+    ref_ids, ref_logits = oracle_run(sd, emb, 8, penalty=1.5)
+    kv = eng.kv_alloc(1, 256)
+    div = check_stream(eng, kv, 0, emb, ref_ids, ref_logits, penalty=1.5)
+    assert len(div) <= 1
+    kv.free()
+
+
+def test_batched_decode_equals_single(setup):
+    """Pages decode together in one batch; every row must equal its own single-sequence run bit for bit."""
+    eng = setup['eng']
+    embs = [prompt(300, 21), prompt(77, 22), prompt(130, 23)]
+    singles = []
+    for e in embs:
+        kv = eng.kv_alloc(1, 512)
+        eng.prefill(kv, 0, e.cuda())
+        for _ in range(6):
+            eng.decode(kv, [0])
+        singles.append(kv.generated(0))
+        kv.free()
+    kv = eng.kv_alloc(4, 512)
+    for i, e in enumerate(embs):
+        eng.prefill(kv, i + 1, e.cuda())           # slots 1..3: slot 0 stays empty on purpose
+    for _ in range(6):
+        eng.decode(kv, [3, 1, 2])                  # arbitrary order
+    for i in range(3):
+        assert kv.generated(i + 1) == singles[i]
+        assert kv.length(i + 1) == embs[i].shape[1] + 6
+    assert kv.length(0) == 0
+    kv.free()
+
+
+def test_kv_reset_and_limits(setup):
+    from callireader_amd._binding import CalliReaderError
+    eng = setup['eng']
+    kv = eng.kv_alloc(1, 64)
+    with pytest.raises(CalliReaderError):
+        eng.prefill(kv, 0, prompt(65, 1).cuda())           # does not fit
+    eng.prefill(kv, 0, prompt(60, 1).cuda())
+    a = kv.generated(0)
+    kv.reset(0)
+    assert kv.length(0) == 0 and kv.generated(0) == []
+    eng.prefill(kv, 0, prompt(60, 1).cuda())
+    assert kv.generated(0) == a
+    with pytest.raises(CalliReaderError):
+        eng.decode(kv, [0, 0])
+    kv.free()
+
+
+def test_embed_splice(setup):
+    from oracle import generate
+    from callireader_amd._binding import CalliReaderError
+    eng, sd = setup['eng'], setup['sd']
+    g = torch.Generator().manual_seed(3)
+    IMG, REF = 8000, 7999
+    ids = torch.randint(0, 7000, (1, 1500), generator=g)
+    ids[0, 10:10 + 512] = IMG
+    ids[0, 1200:1209] = REF
+    ids[0, 1300:1303] = REF
+    vit = torch.randn(2, 256, 4096, generator=g).bfloat16()
+    ref = torch.randn(12, 4096, generator=g).bfloat16()
+    exp = generate.splice_embeddings(sd, ids, vit, ref, IMG, REF)[0]
+    got = eng.embed_splice(ids, vit.cuda(), ref.cuda(), img_id=IMG, ref_id=REF)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), exp)
+    got = eng.embed_splice(ids, vit.cuda(), None, img_id=IMG, ref_id=REF)
+    assert torch.equal(got.cpu(), generate.splice_embeddings(sd, ids, vit, None, IMG, REF)[0])
+    got = eng.embed_splice(ids)
+    assert torch.equal(got.cpu(), generate.splice_embeddings(sd, ids)[0])
+    with pytest.raises(CalliReaderError):
+        eng.embed_splice(ids, vit[:1].cuda(), ref.cuda(), img_id=IMG, ref_id=REF)     # count mismatch
+    with pytest.raises(CalliReaderError):
+        eng.embed_splice(torch.zeros(1, 8, dtype=torch.long), vit.cuda(), None, img_id=IMG)   # no <IMG_CONTEXT>
