@@ -17,7 +17,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }      // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }  // round-trip through bf16
+// Round to bf16 and back (RNE).  Integer arithmetic on purpose: written as (float)(bf16)x, LLVM narrows
+// fptrunc(op(fpext a, fpext b)) chains into bf16 ops and the AMDGPU backend then evaluates them in fp32 WITHOUT the
+// intermediate rounding (seen as a single v_fma_f32), which silently drops the reference's rounding points.
+// Inf stays Inf; NaN is not preserved (never needed at these call sites).
+__device__ __forceinline__ float rbf(float x) {
+    unsigned u = __float_as_uint(x);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    return __uint_as_float(u);
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -1,8 +1,10 @@
 """InternLM2 prefill + greedy decode parity on a real MI355X vs the CPU oracle (2 layers, full width).
 
-Logit tolerance ("fp16 logit tolerance" of BASELINE.json's north_star): the LM head is a bf16 GEMM whose output is
-rounded to bf16 then upcast (modeling_internlm2.py:1081-1082), so one logit ulp at |x|~2 is 2^-7 = 7.8e-3; two
-bf16-eager layers with a different accumulation order add a few ulp: |diff| <= 6e-2 and rel-L2 <= 2e-2.
+Logit tolerance ("fp16 logit tolerance" of BASELINE.json's north_star), calibrated rather than guessed: on these
+very weights/prompts the bf16 CPU oracle differs from an fp32 evaluation of the same network by max 0.085-0.110 and
+rel-L2 1.7e-2-2.3e-2 (logits up to |5.5|; measured in the build container, see DESIGN.md "Tolerances").  A second
+bf16 implementation with another accumulation order cannot be closer to the oracle than the oracle is to exact
+arithmetic, so the bound is that noise floor: |diff| <= 0.12 and rel-L2 <= 2.5e-2.
 Token parity: greedy ids must match the oracle exactly, except where the oracle's own top-2 margin is inside that
 logit tolerance (a near-tie) — then the test continues teacher-forced and reports the position.
 """
@@ -13,7 +15,8 @@ from callireader_amd.config import ModelDims
 from callireader_amd import synthetic
 
 pytestmark = pytest.mark.gpu
-ATOL = 6e-2
+ATOL = 0.12
+RTOL_L2 = 2.5e-2
 
 
 def rel_l2(a, b):
@@ -53,14 +56,14 @@ def check_stream(eng, kv, seq, emb, ref_ids, ref_logits, penalty=1.0):
     diverged = []
     for t in range(len(ref_ids)):
         got, ref = lg.float().cpu().reshape(-1), ref_logits[t]
-        assert rel_l2(got, ref) <= 2e-2, (t, rel_l2(got, ref))
+        assert rel_l2(got, ref) <= RTOL_L2, (t, rel_l2(got, ref))
         assert float((got - ref).abs().max()) <= ATOL, (t, float((got - ref).abs().max()))
         picked = kv.generated(seq)[t]
         if picked != ref_ids[t]:
             # only acceptable at a near-tie of the (penalised) oracle scores
             from oracle.generate import apply_repetition_penalty
             sc = apply_repetition_penalty(ref, ref_ids[:t], penalty)
-            assert float(sc[ref_ids[t]] - sc[picked]) <= 2 * ATOL, (t, picked, ref_ids[t])
+            assert float(sc[ref_ids[t]] - sc[picked]) <= ATOL, (t, picked, ref_ids[t])
             diverged.append(t)
         if t + 1 < len(ref_ids):
             lg = eng.decode(kv, [seq], penalty=penalty, force_tokens=torch.tensor([ref_ids[t]]), want_logits=True)
@@ -93,7 +96,7 @@ def test_free_running_greedy_tokens(setup):
     first_div = next((i for i, (a, b) in enumerate(zip(got, ref_ids)) if a != b), None)
     if first_div is not None:
         top2 = torch.topk(ref_logits[first_div], 2).values
-        assert float(top2[0] - top2[1]) <= 2 * ATOL, f'diverged at {first_div} without a near-tie'
+        assert float(top2[0] - top2[1]) <= ATOL, f'diverged at {first_div} without a near-tie'
     else:
         assert got == ref_ids
     kv.free()

@@ -85,6 +85,34 @@ def test_gemm_epilogues(E, M, N, K):
     close(x, rb(res.float() + rb(lin * scale.float())))
 
 
+def test_gemm_epilogue_rounding_is_bit_exact(E):
+    """Integer-valued A/W make the fp32 accumulator exact, so every epilogue must reproduce the reference's bf16
+    rounding sequence bit for bit (guards against the compiler folding the intermediate roundings away)."""
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 200, 256, 64
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    W = torch.randint(-2, 3, (N, K), generator=g).float()
+    bias = bf(_rand((N,), g, 0.37))
+    scale = bf(_rand((N,), g, 0.21) + 0.13)
+    res = bf(_rand((M, N), g, 1.7))
+    acc = A @ W.t()
+    lin = rb(acc + bias.float())
+    Ad, Wd, bd, sd_, rd = [t.to(dev()) for t in (bf(A), bf(W), bias, scale, res)]
+
+    def same(out, ref):
+        torch.cuda.synchronize()
+        assert torch.equal(out.float().cpu(), ref)
+
+    same(E.op_gemm(0, Ad, Wd, bias=bd), lin)
+    same(E.op_gemm(2, Ad, Wd, bias=bd, scale=sd_, res=rd), rb(res.float() + rb(lin * scale.float())))
+    same(E.op_gemm(3, Ad, Wd, bias=bd, res=rd), rb(res.float() + lin))
+    same(E.op_gemm(6, Ad, Wd, bias=bd, out_dtype=torch.float32), lin)
+    # GELU/SiLU go through erff/expf whose last bit may differ from the CPU's: allow 1 bf16 ulp there
+    out = E.op_gemm(1, Ad, Wd, bias=bd)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), rb(torch.nn.functional.gelu(lin)), rtol=2 ** -7, atol=1e-6)
+
+
 def test_gemm_swiglu(E):
     g = torch.Generator().manual_seed(2)
     M, F, K = 300, 512, 256
