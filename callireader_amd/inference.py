@@ -1,0 +1,88 @@
+"""`python inference.py --tgt ...` with the reference's flags (/root/reference/inference.py:65-130), on the HIP engine.
+
+Differences that the scope forces: character boxes come from a labelme-style JSON next to the image
+(`<image>.json`, the format of examples/0.json) or from --boxes, because the YOLO/OrderFormer front end is out of
+scope; the tokenizer is loaded with transformers' AutoTokenizer from --model (the reference's own tokenizer files).
+"""
+import argparse
+import json
+import os
+
+import torch
+
+from .modeling_internvl_chat import InternVLChatModel, load_boxes_json
+
+IMG_EXT = ('.jpg', '.jpeg', '.png', '.bmp', '.webp')
+
+
+def is_image(p):
+    return os.path.isfile(p) and p.lower().endswith(IMG_EXT)
+
+
+def boxes_for(image_path, boxes_arg=None):
+    cand = boxes_arg or os.path.splitext(image_path)[0] + '.json'
+    if not os.path.exists(cand):
+        raise FileNotFoundError(f'character boxes for {image_path}: expected {cand} (labelme-style, see examples/0.json)')
+    return load_boxes_json(cand)
+
+
+def single_rec(model, tokenizer, generation_config, image_path, prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose, boxes=None):
+    response, history = model.chat_ocr(tokenizer, None, image_path, prompt, generation_config, use_p=use_p, hard_vq=hard_vq,
+                                       drop_zero=drop_zero, repetition_penalty=repetition_penalty, return_history=True,
+                                       verbose=verbose, boxes=boxes_for(image_path, boxes) if use_p else None)
+    print(f'User: {prompt}\nAssistant: {response}')
+    return response
+
+
+def folder_rec(model, tokenizer, generation_config, folder_path, prompt, save_name, use_p, hard_vq, drop_zero, repetition_penalty, verbose):
+    results = []
+    for pic in sorted(f for f in os.listdir(folder_path) if f.lower().endswith(IMG_EXT)):
+        pic_path = os.path.join(folder_path, pic)
+        try:
+            response = single_rec(model, tokenizer, generation_config, pic_path, prompt, use_p, hard_vq, drop_zero,
+                                  repetition_penalty, verbose)
+        except Exception as e:                               # inference.py:55-57
+            print(f'An error has occured:\n{e}')
+            response = 'ERROR!'
+        results.append({'imagePath': pic_path, 'prompt': prompt, 'response': response})
+    if not save_name.endswith('json'):
+        save_name += '_result.json'
+    with open(save_name, 'w', encoding='utf-8') as f:
+        json.dump(results, f, ensure_ascii=False, indent=2)
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='args for inference task')
+    parser.add_argument('--tgt', type=str, help='Recognition target')
+    parser.add_argument('--prompt', type=str, default='这幅书法作品内容是什么？', help='Prompt for recognition')
+    parser.add_argument('--save_name', type=str, default='recognition.json')
+    parser.add_argument('--use_p', type=bool, default=True)          # type=bool kept: any non-empty string is truthy, as upstream
+    parser.add_argument('--hard_vq', type=bool, default=False)
+    parser.add_argument('--drop_zero', type=bool, default=False)
+    parser.add_argument('--verbose', type=bool, default=False)
+    parser.add_argument('--repetition_penalty', type=float, default=1.0)
+    parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
+    parser.add_argument('--params', type=str, default='./params')
+    parser.add_argument('--boxes', type=str, default=None, help='labelme-style JSON with ordered character boxes')
+    args = parser.parse_args(argv)
+    if not isinstance(args.tgt, str):
+        raise ValueError(f'The target should a string, not a instance of {type(args.tgt)}!')
+    from transformers import AutoTokenizer
+    model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16).eval().cuda()
+    tokenizer = AutoTokenizer.from_pretrained(args.model, trust_remote_code=True)
+    generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
+    if is_image(args.tgt):
+        print('Single image recognition mode.')
+        single_rec(model, tokenizer, generation_config, args.tgt, args.prompt, args.use_p, args.hard_vq, args.drop_zero,
+                   args.repetition_penalty, args.verbose, args.boxes)
+    elif os.path.isdir(args.tgt):
+        print('Multiple images recognition mode')
+        os.makedirs('results', exist_ok=True)
+        folder_rec(model, tokenizer, generation_config, args.tgt, args.prompt, os.path.join('results', args.save_name),
+                   args.use_p, args.hard_vq, args.drop_zero, args.repetition_penalty, args.verbose)
+    else:
+        raise ValueError('The target should be either a image path or a folder that contain images!')
+
+
+if __name__ == '__main__':
+    main()

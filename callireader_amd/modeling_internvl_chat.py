@@ -1,0 +1,363 @@
+"""Host-side mirror of the reference's InternVLChatModel for the image->text path.
+
+Same method names, argument meaning, return values and error behaviour as
+/root/reference/InternVL/modeling_internvl_chat.py (extract_feature :299, calli_align :322,
+chat_ocr :649, batch_chat :903, chat :955, generate_origin :1021, generate_ocr :1067), so a
+caller of the reference (inference.py:37-57, evaluate.py) can switch classes.  All tensor
+math runs in libcallireader_hip.so through `Engine`; this file only builds prompts, moves
+ids and pixels, and drives the greedy loop.  There is no PyTorch compute fallback.
+
+Out of scope here: the YOLO detector and the OrderFormer sorter.  Where the
+reference takes `detect_model`, this class takes either a callable `img -> ordered xyxy boxes`
+or explicit `boxes=`.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, EOS_TOKEN_ID
+from .conversation import get_conv_template
+from .engine import Engine
+from .preprocess import load_image, load_image_2
+
+
+class InternVLChatModel:
+    main_input_name = 'pixel_values'
+
+    def __init__(self, dims: ModelDims = None, device=0, max_tokens=8192, max_pages=1):
+        self.dims = dims or ModelDims.full()
+        self.engine = Engine(self.dims, device=device, max_pos=min(self.dims.max_pos, max(max_tokens, 64)))
+        self.device = self.engine.device
+        self.template = 'internlm2-chat'
+        self.num_image_token = self.dims.tokens_per_tile                    # :146
+        self.downsample_ratio = self.dims.downsample_ratio
+        self.ps_version = 'v2'
+        self.select_layer = -1
+        self.img_context_token_id = None                                    # :192
+        self.conv_template = get_conv_template(self.template)
+        self.system_message = self.conv_template.system_message            # :194
+        self.max_tokens = max_tokens
+        self.max_pages = max_pages
+        self._kv = None
+        self._ready = False
+
+    # ---- construction --------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, sd, dims=None, **kw):
+        m = cls(dims, **kw)
+        m.engine.load_state_dict(sd)
+        m._finish()
+        return m
+
+    @classmethod
+    def from_synthetic(cls, dims=None, seed=0, parts=('vit', 'mlp1', 'resampler', 'vq', 'llm'), **kw):
+        """Seeded random weights of the checkpoint's architecture, drawn on the GPU tensor by tensor."""
+        from . import synthetic
+        m = cls(dims, **kw)
+        for k, v in synthetic.iter_state_dict(m.dims, parts=parts, seed=seed, device=m.device):
+            m.engine.load_weight(k, v)
+            del v
+        m._finish()
+        return m
+
+    @classmethod
+    def from_pretrained(cls, path, params_dir='./params', torch_dtype=torch.bfloat16, **kw):
+        """HF sharded safetensors (model.safetensors.index.json) + params/gauss_norm_mu_sigma.pth, as
+        AutoModel.from_pretrained(INTERNVL_PATH, ...) does in inference.py:85-89 / __init__ :153-159."""
+        from .weights import load_checkpoint
+        m = cls(kw.pop('dims', None), **kw)
+        load_checkpoint(m.engine, path, params_dir)
+        m._finish()
+        return m
+
+    def _finish(self):
+        self.engine.load_rope()
+        self.engine.finalize()
+        self._ready = True
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def kv(self):
+        if self._kv is None:
+            self._kv = self.engine.kv_alloc(self.max_pages, self.max_tokens)
+        return self._kv
+
+    # ---- the * stages --------------------------------------------------------------------------
+    def extract_feature(self, pixel_values):
+        """:299-319  (T,3,448,448) -> (T,256,4096)"""
+        return self.engine.extract_feature(pixel_values)
+
+    def resampler(self, image_embeddings):
+        """models/perceiver_resampler.py:81-100  (T,256,4096) -> (T,3,4096)"""
+        return self.engine.resample(image_embeddings)
+
+    def align_tiles(self, pixel_values, drop_zero=False, use_hard_vector_quant=False, verbose=False):
+        """The tile path of calli_align after the boxes are known (:587-640):
+        extract_feature -> resampler -> vq_cos_sim -> (hard VQ) -> (drop_zero) -> sigma/mu de-normalisation.
+        Returns (back_to_origin_flat (n,4096), indices (T,3))."""
+        st = time.time()
+        image_embeddings = self.extract_feature(pixel_values)
+        output = self.resampler(image_embeddings)
+        outs = self.engine.vq(output, with_cos=use_hard_vector_quant)
+        if use_hard_vector_quant:
+            indices, cos_sim_values = outs
+            print('Dynamic vector quantization...')                          # :610
+        else:
+            indices, cos_sim_values = outs, None
+        back = self.engine.denorm(output, indices, cos_sim_values, drop_zero=drop_zero, hard_vq=use_hard_vector_quant)
+        if verbose:
+            torch.cuda.synchronize()
+            print(f'extract feat + resampler + vq {time.time() - st:.2f}s')
+        # the reference returns vq_cos_sim's squeezed indices: shape (3,) for a single tile (similarity.py:27)
+        return back, (indices.squeeze(0) if indices.shape[0] == 1 else indices)
+
+    def calli_align(self, img_path, detect_model, drop_zero=False, use_hard_vector_quant=False, save_path=None,
+                    verbose=False, boxes=None):
+        """:322-640.  Boxes come from `boxes=` or from `detect_model(img)` (ordered xyxy, pixels)."""
+        if img_path is None:
+            return None, None                                               # :554-555
+        img = Image.open(img_path).convert('RGB') if isinstance(img_path, str) else img_path.convert('RGB')
+        if boxes is None:
+            if not callable(detect_model):
+                raise NotImplementedError('the YOLO + OrderFormer front end is outside this engine (SURVEY.md 8f-4): '
+                                          'pass boxes=[(x1,y1,x2,y2),...] or a callable detect_model(img)')
+            boxes = detect_model(img)
+        arr = np.array(img)
+        tiles = []
+        for xyxy in boxes:                                                  # :580-583
+            x1, y1, x2, y2 = int(xyxy[0]), int(xyxy[1]), int(xyxy[2]), int(xyxy[3])
+            tiles.append(load_image_2(Image.fromarray(arr[y1:y2, x1:x2])).to(torch.bfloat16))
+        results = torch.cat(tiles).to(self.device)                          # :585
+        return self.align_tiles(results, drop_zero, use_hard_vector_quant, verbose)
+
+    # ---- generation ----------------------------------------------------------------------------
+    def _greedy(self, input_embeds, max_new_tokens, eos_token_id, repetition_penalty, check_every=16):
+        """transformers 4.45.2 GenerationMixin._sample with do_sample=False, num_beams=1, for ONE sequence:
+        returns only the new ids, EOS included (oracle/generate.py documents the semantics)."""
+        kv = self.kv()
+        kv.reset(0)
+        if input_embeds.shape[0] + max_new_tokens > self.max_tokens:
+            raise ValueError(f'prompt of {input_embeds.shape[0]} tokens + {max_new_tokens} new exceeds max_tokens={self.max_tokens}')
+        self.engine.prefill(kv, 0, input_embeds, penalty=repetition_penalty)
+        n = 1
+        while n < max_new_tokens:
+            steps = min(check_every, max_new_tokens - n)
+            if eos_token_id is not None and eos_token_id in kv.generated(0):
+                break
+            for _ in range(steps):
+                self.engine.decode(kv, [0], penalty=repetition_penalty)
+            n += steps
+        ids = kv.generated(0)[:max_new_tokens]
+        if eos_token_id is not None and eos_token_id in ids:
+            ids = ids[:ids.index(eos_token_id) + 1]       # ids past EOS were speculative; the reference stops here
+        return torch.tensor([ids], dtype=torch.long, device=self.device)
+
+    @staticmethod
+    def _gen_args(generate_kwargs):
+        if generate_kwargs.get('num_beams', 1) != 1 or generate_kwargs.get('do_sample', False):
+            raise NotImplementedError('the CalliReader path is greedy (inference.py:92-96): num_beams=1, do_sample=False')
+        return generate_kwargs.get('max_new_tokens', 1024), generate_kwargs.get('eos_token_id', EOS_TOKEN_ID)
+
+    @torch.no_grad()
+    def generate_ocr(self, pixel_values=None, input_ids=None, attention_mask=None, visual_features=None,
+                     generation_config=None, reference_embeds=None, output_hidden_states=None, return_dict=None,
+                     repetition_penalty=1.5, **generate_kwargs):
+        """:1067-1122"""
+        assert self.img_context_token_id is not None                        # :1081
+        if input_ids.shape[0] != 1:
+            raise NotImplementedError('generate_ocr handles one page per call, as chat_ocr does')
+        if pixel_values is not None:
+            vit_embeds = visual_features if visual_features is not None else self.extract_feature(pixel_values)
+            ids = input_ids.reshape(-1)
+            assert (ids == self.img_context_token_id).sum() != 0            # :1095
+            if reference_embeds is not None:
+                assert (ids == ALIGNED_TOKEN_ID).sum() != 0                 # :1101
+            input_embeds = self.engine.embed_splice(ids, vit_embeds, reference_embeds,
+                                                    img_id=self.img_context_token_id, ref_id=ALIGNED_TOKEN_ID)
+        else:
+            input_embeds = self.engine.embed_splice(input_ids.reshape(-1))  # :1107
+        max_new, eos = self._gen_args(generate_kwargs)
+        return self._greedy(input_embeds, max_new, eos, repetition_penalty)
+
+    @torch.no_grad()
+    def generate_origin(self, pixel_values=None, input_ids=None, attention_mask=None, visual_features=None,
+                        generation_config=None, output_hidden_states=None, return_dict=None, **generate_kwargs):
+        """:1021-1065 (no pseudo-tokens, no repetition penalty unless passed)"""
+        penalty = generate_kwargs.pop('repetition_penalty', 1.0)
+        return self.generate_ocr(pixel_values, input_ids, attention_mask, visual_features, generation_config, None,
+                                 output_hidden_states, return_dict, repetition_penalty=penalty, **generate_kwargs)
+
+    # ---- chat API ------------------------------------------------------------------------------
+    def _build_query(self, question, history, num_patches_list, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN):
+        template = get_conv_template(self.template)
+        template.system_message = self.system_message
+        history = [] if history is None else history
+        for (old_question, old_answer) in history:
+            template.append_message(template.roles[0], old_question)
+            template.append_message(template.roles[1], old_answer)
+        template.append_message(template.roles[0], question)
+        template.append_message(template.roles[1], None)
+        query = template.get_prompt()
+        for num_patches in num_patches_list:
+            image_tokens = IMG_START_TOKEN + IMG_CONTEXT_TOKEN * self.num_image_token * num_patches + IMG_END_TOKEN
+            query = query.replace('<image>', image_tokens, 1)
+        return query, template, history
+
+    def chat(self, tokenizer, pixel_values, question, generation_config, history=None, return_history=False,
+             num_patches_list=None, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+             verbose=False):
+        """:955-1018"""
+        if history is None and pixel_values is not None and '<image>' not in question:
+            question = '<image>\n' + question
+        if num_patches_list is None:
+            num_patches_list = [pixel_values.shape[0]] if pixel_values is not None else []
+        assert pixel_values is None or len(pixel_values) == sum(num_patches_list)       # :965
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        query, template, history = self._build_query(question, history, num_patches_list, IMG_START_TOKEN,
+                                                     IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+        model_inputs = tokenizer(query, return_tensors='pt')
+        generation_config = dict(generation_config)
+        generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
+        out = self.generate_origin(pixel_values=pixel_values, input_ids=model_inputs['input_ids'],
+                                   attention_mask=model_inputs['attention_mask'], **generation_config)
+        response = tokenizer.batch_decode(out, skip_special_tokens=True)[0]
+        response = response.split(template.sep)[0].strip()
+        history.append((question, response))
+        return (response, history) if return_history else response
+
+    def chat_ocr(self, tokenizer, detect_model, img_path, questions, generation_config, num_patches_list=None,
+                 history=None, return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>',
+                 IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]', verbose=False, image_counts=None,
+                 batch=False, use_p=True, drop_zero=False, hard_vq=False, repetition_penalty=1.5, region_wise=False,
+                 boxes=None):
+        """:649-762"""
+        pixel_values = None
+        sub_img = None
+        if img_path is not None:
+            try:
+                if region_wise:
+                    import re
+                    img = np.array(Image.open(img_path).convert('RGB'))
+                    x1, x2, y1, y2 = [int(n) for n in re.findall(r'\d+', questions)]     # find_coordinates :642-648
+                    sub_img = Image.fromarray(img[y1:y2, x1:x2])
+                    questions = '输出图片中所有文字:'
+                    pixel_values = load_image(sub_img).to(torch.bfloat16).to(self.device)
+                else:
+                    pixel_values = load_image(img_path).to(torch.bfloat16).to(self.device)
+            except Exception:
+                raise FileNotFoundError                                         # :670-671
+        out_tokens = None
+        if use_p:
+            if region_wise:
+                try:
+                    out_tokens, indices = self.calli_align(sub_img, detect_model, drop_zero=drop_zero,
+                                                           use_hard_vector_quant=hard_vq, verbose=verbose, boxes=boxes)
+                except Exception:
+                    return '检测失败'                                            # :676-679
+            else:
+                out_tokens, indices = self.calli_align(img_path, detect_model, drop_zero=drop_zero,
+                                                       use_hard_vector_quant=hard_vq, verbose=verbose, boxes=boxes)
+        question = questions
+        if pixel_values is not None and '<image>' not in questions:
+            question = '<image>\n' + questions                                  # :690-691
+        if history is None and use_p and ALIGNED_TOKEN not in question:
+            question = question + ALIGNED_TOKEN * out_tokens.shape[0]           # :698-699
+        if num_patches_list is None:
+            num_patches_list = [pixel_values.shape[0]] if pixel_values is not None else []
+        assert pixel_values is None or len(pixel_values) == sum(num_patches_list)          # :702
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        query, template, history = self._build_query(question, history, num_patches_list, IMG_START_TOKEN,
+                                                     IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+        model_inputs = tokenizer(query, return_tensors='pt')
+        generation_config = dict(generation_config)
+        generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)   # :709,732
+        out = self.generate_ocr(pixel_values=pixel_values, input_ids=model_inputs['input_ids'],
+                                attention_mask=model_inputs['attention_mask'],
+                                reference_embeds=out_tokens if use_p else None,
+                                repetition_penalty=repetition_penalty, **generation_config)
+        response = tokenizer.batch_decode(out, skip_special_tokens=True)[0]
+        response = response.split(template.sep)[0].strip()                      # :752-753
+        history.append((question, response))
+        return (response, history) if return_history else response
+
+    def batch_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
+                   return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+                   verbose=False, image_counts=None):
+        """:903-951.  The reference left-pads and runs one padded batch; here every query is prefilled at its own
+        length and the pages then decode together (cr_llm_decode), which gives each row exactly its unpadded result."""
+        if history is not None or return_history:
+            print('Now multi-turn chat is not supported in batch_chat.')
+            raise NotImplementedError
+        if image_counts is not None:
+            num_patches_list = image_counts
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        generation_config = dict(generation_config)
+        embeds, off = [], 0
+        feats = self.extract_feature(pixel_values) if pixel_values is not None else None
+        for idx, num_patches in enumerate(num_patches_list):
+            question = questions[idx]
+            if pixel_values is not None and '<image>' not in question:
+                question = '<image>\n' + question
+            query, template, _ = self._build_query(question, None, [num_patches], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+            ids = tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1)
+            embeds.append(self.engine.embed_splice(ids, feats[off:off + num_patches] if feats is not None else None,
+                                                   img_id=self.img_context_token_id))
+            off += num_patches
+        generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
+        max_new, eos = self._gen_args(generation_config)
+        outs = self.generate_pages(embeds, max_new, eos, generation_config.get('repetition_penalty', 1.0))
+        responses = [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0] for o in outs]
+        return [r.split(template.sep)[0].strip() for r in responses]
+
+    # ---- page-parallel generation (new: the reference decodes one page at a time) ---------------
+    def generate_pages(self, embeds_list, max_new_tokens=1024, eos_token_id=EOS_TOKEN_ID, repetition_penalty=1.0,
+                       check_every=16):
+        """Prefill every page, then decode all unfinished pages as ONE batch per step: the 14.7 GB of LLM weights are
+        streamed once per step for all pages.  Per page the ids equal the single-page greedy result."""
+        P = len(embeds_list)
+        if self._kv is None or self._kv.n_seqs < P:
+            if self._kv is not None:
+                self._kv.free()
+            self.max_pages = max(P, self.max_pages)
+            self._kv = self.engine.kv_alloc(self.max_pages, self.max_tokens)
+        kv = self._kv
+        for i, e in enumerate(embeds_list):
+            kv.reset(i)
+            self.engine.prefill(kv, i, e, penalty=repetition_penalty)
+        live = list(range(P))
+        n = 1
+        done = {}
+        while n < max_new_tokens and live:
+            steps = min(check_every, max_new_tokens - n)
+            for _ in range(steps):
+                self.engine.decode(kv, live, penalty=repetition_penalty)
+            n += steps
+            if eos_token_id is not None:
+                for i in list(live):
+                    ids = kv.generated(i)
+                    if eos_token_id in ids:
+                        done[i] = ids[:ids.index(eos_token_id) + 1]
+                        live.remove(i)
+        outs = []
+        for i in range(P):
+            ids = done.get(i)
+            if ids is None:
+                ids = kv.generated(i)[:max_new_tokens]
+                if eos_token_id is not None and eos_token_id in ids:
+                    ids = ids[:ids.index(eos_token_id) + 1]
+            outs.append(ids)
+        return outs
+
+
+def load_boxes_json(path):
+    from .preprocess import boxes_from_labelme
+    with open(path, 'r', encoding='utf-8') as f:
+        return boxes_from_labelme(json.load(f))
