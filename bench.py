@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the CalliReader image->text hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Metric (BASELINE.json): calligraphy pages/sec through ViT + resampler + LLM greedy decode.
+One "step" = one batch of synthetic pages per GPU through the whole path:
+  page shape = examples/0.jpg of the reference: 11 page tiles + 96 character tiles of 448x448 (107 ViT tiles),
+  prompt of 3164 tokens (11*256 visual + 96*3 pseudo-tokens + 60 text), NEW_TOKENS greedy tokens
+  (random weights never emit EOS; 128 ~ the 96-character transcription of that page);
+  visual stage on this rank's contiguous shard of the batch's tiles -> (N > 1) all-gather of the embeddings over
+  RCCL -> embedding splice + prefill for the pages this rank owns -> batched decode of those pages.
+Inputs (pixels, token ids, weights) are resident in HBM before the timed region; weights are seeded random
+(no checkpoint is available offline).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PAGE_TILES, CHAR_TILES, TEXT_TOKENS = 11, 96, 60
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0          # HBM3E spec, same table
+
+
+def build_ids(n_page_tiles, n_char_tiles, text_tokens, img_id, ref_id, seed):
+    g = torch.Generator().manual_seed(seed)
+    head = torch.randint(100, 60000, (text_tokens // 2,), generator=g)
+    tail = torch.randint(100, 60000, (text_tokens - text_tokens // 2,), generator=g)
+    return torch.cat([head, torch.full((n_page_tiles * 256,), img_id), torch.full((n_char_tiles * 3,), ref_id), tail])
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference's eager path) on a bounded sample of the same page workload,
+    extrapolated linearly to one page.  Reported next to the GPU number; it is not the target."""
+    from callireader_amd.config import ModelDims
+    from callireader_amd import synthetic
+    from oracle import vision, calli_align, internlm2
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    dims = ModelDims.full()
+    t_all = time.time()
+    with torch.no_grad():
+        sd = synthetic.make_state_dict(dims, parts=('vit', 'mlp1'), seed=0)
+        px = synthetic.make_pixels(2, seed=0)
+        vision.extract_feature(sd, px[:1], 1)                                      # warm-up (1 layer)
+        t0 = time.time(); feat = vision.extract_feature(sd, px, dims.vit_layers); t_vit = (time.time() - t0) / 2
+        del sd
+        rdims = ModelDims.reduced(rs_depth=1)
+        sd = synthetic.make_state_dict(rdims, parts=('resampler',), seed=0)
+        t0 = time.time(); calli_align.resampler_forward(sd, feat, 1); t_rs = (time.time() - t0) / 2 * dims.rs_depth
+        del sd
+        ldims = ModelDims.reduced(llm_layers=1, vocab=1024)
+        sd = synthetic.make_state_dict(ldims, parts=('llm',), seed=0)
+        S = 512
+        emb = (torch.randn(1, S, 4096) * 0.02).bfloat16()
+        rope = internlm2.rope_tables(128, seq_len=4096)
+        t0 = time.time(); _, past = internlm2.model_forward(sd, 1, inputs_embeds=emb, rope=rope, all_logits=False)
+        t_pre = (time.time() - t0) / S * dims.llm_layers                           # s per prompt token, 32 layers
+        t0 = time.time()
+        for _ in range(4):
+            _, past = internlm2.model_forward(sd, 1, input_ids=torch.tensor([[5]]), past=past, rope=rope)
+        t_dec = (time.time() - t0) / 4 * dims.llm_layers                           # s per new token, 32 layers
+    S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
+    page_s = t_vit * (PAGE_TILES + CHAR_TILES) + t_rs * CHAR_TILES + t_pre * S_page + t_dec * NEW_TOKENS
+    return {'value': 1.0 / page_s, 'unit': 'pages/s', 'cores': cores, 'kind': 'port',
+            'cpu': platform.processor() or platform.machine(),
+            'sample': (f'oracle bf16 eager: ViT+mlp1 24 layers on 2 tiles ({t_vit:.2f} s/tile), resampler 1 of 4 layers on 2 tiles, '
+                       f'InternLM2 1 of 32 layers prefill {S} tokens ({t_pre * 1e3:.1f} ms/token x32) + 4 decode steps '
+                       f'({t_dec * 1e3:.0f} ms/token x32); extrapolated linearly to one page (107 tiles, {S_page} prompt tokens, '
+                       f'{NEW_TOKENS} new tokens) = {page_s:.0f} s/page; sample wall {time.time() - t_all:.0f} s')}
+
+
+NEW_TOKENS = 128
+
+
+def main():
+    global NEW_TOKENS
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--pages', type=int, default=8, help='pages per GPU per step')
+    ap.add_argument('--new-tokens', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-vit-extra', action='store_true')
+    args = ap.parse_args()
+    NEW_TOKENS = args.new_tokens
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from callireader_amd.config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID
+    from callireader_amd import synthetic, _binding as B
+    from callireader_amd.modeling_internvl_chat import InternVLChatModel
+    from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages
+
+    dims = ModelDims.full()
+    P = args.pages
+    n_pages = P * world
+    S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
+    model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=S_page + NEW_TOKENS + 64, max_pages=P)
+    model.img_context_token_id = IMG_CONTEXT_TOKEN_ID
+    eng = model.engine
+
+    # ---- synthetic inputs, resident in HBM ----
+    pt_lo, pt_hi = shard_range(n_pages * PAGE_TILES, world, rank)
+    ct_lo, ct_hi = shard_range(n_pages * CHAR_TILES, world, rank)
+    page_px = synthetic.make_pixels(pt_hi - pt_lo, seed=10 + rank, device=dev)
+    char_px = synthetic.make_pixels(ct_hi - ct_lo, seed=20 + rank, device=dev)
+    mine = owned_pages(n_pages, world, rank)
+    ids = [build_ids(PAGE_TILES, CHAR_TILES, TEXT_TOKENS, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, 1000 + p).to(dev) for p in mine]
+
+    def step():
+        vit_local = model.extract_feature(page_px)                                   # (tiles,256,4096)
+        pseudo_local, _ = model.align_tiles(char_px)                                 # (3*tiles,4096)
+        vit_all = all_gather_rows(vit_local, n_pages * PAGE_TILES)
+        pseudo_all = all_gather_rows(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)
+        embeds = []
+        for j, p in enumerate(mine):
+            v = vit_all[p * PAGE_TILES:(p + 1) * PAGE_TILES]
+            r = pseudo_all[p * CHAR_TILES:(p + 1) * CHAR_TILES]
+            embeds.append(eng.embed_splice(ids[j], v, r, img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID))
+        outs = model.generate_pages(embeds, max_new_tokens=NEW_TOKENS, eos_token_id=None)
+        assert all(len(o) == NEW_TOKENS for o in outs)
+        return outs
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    B.check(B.lib.cr_profile(eng._h, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    B.check(B.lib.cr_profile(eng._h, 0))
+    import ctypes as C
+    prof = (C.c_double * 8)()
+    B.check(B.lib.cr_profile_read(eng._h, prof))
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_pages / (elapsed / args.steps)
+        big_n, big_ms, big_fl = prof[0], prof[1], prof[2]
+        sm_n, sm_ms, sm_fl, sm_by = prof[4], prof[5], prof[6], prof[7]
+        achieved = big_fl / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
+        result = {
+            'metric': 'calligraphy pages/sec (ViT+resampler+LLM greedy)', 'value': round(value, 4), 'unit': 'pages/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'full page path, {P} pages/GPU/step of the examples/0.jpg shape (11 page + 96 char tiles 448x448, '
+                                   f'{S_page}-token prompt, {NEW_TOKENS} greedy tokens, repetition_penalty 1.0); InternVL2-8B shapes '
+                                   '(InternViT-300M 24L + mlp1 + PerceiverResampler 4L + 92553-row cosine VQ + InternLM2.5-7B 32L), random-init bf16 weights',
+                       'pages_per_gpu': P, 'tiles_per_page': PAGE_TILES + CHAR_TILES, 'prompt_tokens': S_page, 'new_tokens': NEW_TOKENS,
+                       'parallelism': f'tile shards + RCCL all-gather of visual embeds, pages round-robin, dp{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm128_kernel (bf16 MFMA GEMM, launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill)',
+                         'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                         'launches': int(big_n), 'avg_launch_ms': round(big_ms / max(big_n, 1), 4),
+                         'flops_per_launch': round(big_fl / max(big_n, 1), 1),
+                         'how': 'HIP events around every launch on the launch stream during the timed steps (cr_profile)'},
+            'decode_gemm': {'bound': 'hbm', 'kernel': 'gemm128_kernel launches with M < 1024 (batched decode, resampler rows)',
+                            'achieved': round(sm_by / (sm_ms * 1e-3) / 1e9, 1) if sm_ms > 0 else 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                            'frac': round(sm_by / (sm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sm_ms > 0 else 0.0,
+                            'launches': int(sm_n), 'kernel_ms_per_step': round(sm_ms / args.steps, 2)},
+            'gemm_big_ms_per_step': round(big_ms / args.steps, 2),
+        }
+
+    # ---- extras on rank 0 at N == 1: BASELINE config 2 (ViT only, 32 tiles) and the CPU baseline ----
+    if rank == 0 and world == 1:
+        if not args.no_vit_extra:
+            px32 = synthetic.make_pixels(32, seed=0, device=dev)
+            eng.vit_forward(px32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eng.vit_forward(px32)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            result['vit_config2'] = {'workload': 'InternViT-300M encoder only, 32 tiles 448x448, bf16', 'tiles_per_s': round(32 / dt, 1),
+                                     'ms': round(dt * 1e3, 2), 'tflops': round(32 * 723.6e9 / dt / 1e12, 1),
+                                     'mfma_frac': round(32 * 723.6e9 / dt / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if not args.no_cpu_baseline:
+            del model
+            result['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result, ensure_ascii=False), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

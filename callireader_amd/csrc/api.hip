@@ -47,6 +47,29 @@ int ws_ensure(cr_ctx* c, size_t bytes) {
     return CR_OK;
 }
 
+int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
+    cr_ctx::ProfRec rec{};
+    const bool on = c->prof && c->prof_recs.size() < 200000;
+    if (on) {
+        for (hipEvent_t* e : {&rec.a, &rec.b}) {
+            if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) return cr_fail(CR_ERR_HIP, "hipEventCreate");
+        }
+        hipEventRecord(rec.a, st);
+    }
+    const int r = launch_gemm(epi, p, st);
+    if (on) {
+        hipEventRecord(rec.b, st);
+        const double n_out = epi == EPI_SWIGLU ? p.N / 2.0 : p.N;
+        rec.flops = 2.0 * p.M * (double)p.N * p.K;
+        rec.bytes = 2.0 * ((double)p.N * p.K + (double)p.M * p.K) + (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out;
+        rec.big = p.M >= 1024;
+        c->prof_recs.push_back(rec);
+    }
+    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) rejected or failed to launch", epi, p.M, p.N, p.K);
+    return CR_OK;
+}
+
 static size_t dtype_size(int dt) { return dt == CR_BF16 ? 2 : dt == CR_F32 ? 4 : dt == CR_I64 ? 8 : dt == CR_I32 ? 4 : 0; }
 
 extern "C" {
@@ -74,6 +97,8 @@ int cr_destroy(cr_ctx* c) {
     for (auto& kv : c->w) if (kv.second.ptr) hipFree(kv.second.ptr);
     if (c->ws) hipFree(c->ws);
     if (c->scratch) hipFree(c->scratch);
+    for (auto& r : c->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto e : c->prof_pool) hipEventDestroy(e);
     delete c;
     return CR_OK;
 }
@@ -99,6 +124,28 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
     if (src_is_host) CR_HIP(hipStreamSynchronize((hipStream_t)stream));   // caller may free host memory right away
     c->w[name] = t;
     c->finalized = false;
+    return CR_OK;
+}
+
+int cr_profile(cr_ctx* c, int enable) {
+    if (!c) return cr_fail(CR_ERR_ARG, "cr_profile: null context");
+    c->prof = enable != 0;
+    return CR_OK;
+}
+
+int cr_profile_read(cr_ctx* c, double* out) {
+    if (!c || !out) return cr_fail(CR_ERR_ARG, "cr_profile_read: null argument");
+    CR_HIP(hipSetDevice(c->device));
+    CR_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 8; i++) out[i] = 0.0;
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+        double* o = out + (r.big ? 0 : 4);
+        o[0] += 1.0; o[1] += ms; o[2] += r.flops; if (!r.big) o[3] += r.bytes;
+        c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
+    }
+    c->prof_recs.clear();
     return CR_OK;
 }
 

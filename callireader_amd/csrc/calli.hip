@@ -156,14 +156,12 @@ __global__ __launch_bounds__(256) void denorm_kernel(const bf16* __restrict__ x,
     }
 }
 
-int gemm(int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
+int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
          const bf16* res, int64_t ldr, int M, int N, int K, hipStream_t st) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.res = res; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K;
-    int r = launch_gemm(epi, p, st);
-    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) failed", epi, M, N, K);
-    return CR_OK;
+    return ctx_gemm(c, epi, p, st);
 }
 
 int ln(const bf16* in, bf16* out, const bf16* g, const bf16* b, int64_t rows, int in_group, int out_group, int out_off, hipStream_t st) {
@@ -230,13 +228,13 @@ int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
         CR_TRY(ln(x, kv_in, nmw, nmb, (int64_t)T * 256, 256, NKV, 0, st));
         CR_TRY(ln(learns, kv_in, nlw, nlb, R, NQ, NKV, 256, st));
         CR_TRY(ln(learns, lnl, nlw, nlb, R, 0, 0, 0, st));
-        CR_TRY(gemm(EPI_STORE, lnl, D, wq, D, q, INNER, nullptr, nullptr, 0, (int)R, INNER, D, st));              // :35
-        CR_TRY(gemm(EPI_STORE, kv_in, D, wkv, D, kv, 2 * INNER, nullptr, nullptr, 0, T * NKV, 2 * INNER, D, st));  // :39
+        CR_TRY(gemm(c, EPI_STORE, lnl, D, wq, D, q, INNER, nullptr, nullptr, 0, (int)R, INNER, D, st));              // :35
+        CR_TRY(gemm(c, EPI_STORE, kv_in, D, wkv, D, kv, 2 * INNER, nullptr, nullptr, 0, T * NKV, 2 * INNER, D, st));  // :39
         hipLaunchKernelGGL(perceiver_attn_kernel, dim3(T, HEADS), dim3(64), 0, st, q, kv, ao, 0.125f);
-        CR_TRY(gemm(EPI_RES, ao, INNER, wo, INNER, learns, D, nullptr, learns, D, (int)R, D, INNER, st));          // :51 + :97
+        CR_TRY(gemm(c, EPI_RES, ao, INNER, wo, INNER, learns, D, nullptr, learns, D, (int)R, D, INNER, st));          // :51 + :97
         CR_TRY(ln(learns, lnl, fw0, fb0, R, 0, 0, 0, st));                                                         // FeedForward :134
-        CR_TRY(gemm(EPI_GELU, lnl, D, fw1, D, ff, 4 * D, fb1, nullptr, 0, (int)R, 4 * D, D, st));
-        CR_TRY(gemm(EPI_RES, ff, 4 * D, fw3, 4 * D, learns, D, fb3, learns, D, (int)R, D, 4 * D, st));             // :98
+        CR_TRY(gemm(c, EPI_GELU, lnl, D, fw1, D, ff, 4 * D, fb1, nullptr, 0, (int)R, 4 * D, D, st));
+        CR_TRY(gemm(c, EPI_RES, ff, 4 * D, fw3, 4 * D, learns, D, fb3, learns, D, (int)R, D, 4 * D, st));             // :98
     }
     const bf16 *nw = W(c, "resampler.norm.weight"), *nb = W(c, "resampler.norm.bias");
     if (!nw || !nb) return CR_ERR_STATE;
@@ -259,7 +257,7 @@ int cr_vq(cr_ctx* c, const void* in, int n, int64_t* idx, void* cosv, void* stre
     bf16* xn = ar.take<bf16>((size_t)n * D);
     bf16* sim = ar.take<bf16>((size_t)n * ld);
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(n), dim3(256), 0, st, (const bf16*)in, xn, (int64_t)n);
-    CR_TRY(gemm(EPI_STORE, xn, D, (const bf16*)tb->ptr, D, sim, ld, nullptr, nullptr, 0, n, V, D, st));
+    CR_TRY(gemm(c, EPI_STORE, xn, D, (const bf16*)tb->ptr, D, sim, ld, nullptr, nullptr, 0, n, V, D, st));
     hipLaunchKernelGGL(row_argmax_bf16_kernel, dim3(n), dim3(256), 0, st, sim, ld, V, idx, (bf16*)cosv);
     CR_HIP(hipGetLastError());
     return CR_OK;

@@ -27,7 +27,15 @@ struct cr_ctx {
     // small persistent device scratch (counters, argmax partials)
     char* scratch = nullptr;
     size_t scratch_bytes = 0;
+    // measurement (cr_profile): event pairs around GEMM launches
+    bool prof = false;
+    struct ProfRec { hipEvent_t a, b; double flops, bytes; int big; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
 };
+
+// GEMM launch used by every stage: validates, launches, and (when profiling) brackets the launch with events.
+int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st);
 
 void cr_set_error(const char* fmt, ...);
 int cr_fail(int code, const char* fmt, ...);

@@ -189,13 +189,11 @@ __global__ __launch_bounds__(256) void interleave8_kernel(const bf16* __restrict
     dp[threadIdx.x + 256] = sp[threadIdx.x + 256];
 }
 
-int gemm(int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
+int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
          int M, int N, int K, hipStream_t st) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.res = res; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
-    int r = launch_gemm(epi, p, st);
-    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) failed", epi, M, N, K);
-    return CR_OK;
+    return ctx_gemm(c, epi, p, st);
 }
 
 int rms(const bf16* in, int64_t ld_in, bf16* out, const bf16* w, int64_t rows, float eps, hipStream_t st) {
@@ -232,7 +230,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int 
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
         CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
-        CR_TRY(gemm(EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
+        CR_TRY(gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
         hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, pos0, seq0,
                            decode ? d_seqs : nullptr, decode ? kv->d_len : nullptr, kv->max_tokens);
         AttnParams ap{};
@@ -251,10 +249,10 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int 
             ap.seq_map = d_seqs; ap.sk_arr = kv->d_len; ap.sk_add = 1;
             if (launch_flash_attn(ap, HD, false, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
         }
-        CR_TRY(gemm(EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+        CR_TRY(gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
         CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
-        CR_TRY(gemm(EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
-        CR_TRY(gemm(EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
+        CR_TRY(gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
+        CR_TRY(gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
     }
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -391,7 +389,7 @@ int cr_llm_prefill(cr_ctx* c, cr_kv* kv, int seq, const void* embeds, int S, flo
     if (!nw || !ow) return CR_ERR_STATE;
     // only the last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)
     CR_TRY(rms(x + (size_t)(S - 1) * D, D, hl, nw, 1, c->d.rms_eps, st));
-    CR_TRY(gemm(EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, 1, V, D, st));
+    CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, 1, V, D, st));
     if (last_logits) CR_HIP(hipMemcpyAsync(last_logits, lg, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, seq, (const int32_t*)nullptr,
                        kv->d_gen, kv->d_ngen, kv->d_len, kv->gen_cap, S);
@@ -427,7 +425,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, table, force_tokens, kv->d_seqs, kv->d_gen, kv->d_ngen, kv->gen_cap, x);
     CR_TRY(run_layers(c, kv, x, n, true, 0, 0, kv->d_seqs, st));
     CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
-    CR_TRY(gemm(EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
+    CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
     if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(pick_kernel, dim3(n), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, 0, kv->d_seqs, kv->d_gen, kv->d_ngen,
                        kv->d_len, kv->gen_cap, 1);

@@ -28,14 +28,12 @@ int vit_finalize(cr_ctx* c, hipStream_t st) {
     return CR_OK;
 }
 
-static int gemm(int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
+static int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
                 const bf16* scale, const bf16* res, int64_t ldr, int M, int N, int K, int group, hipStream_t st) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.scale = scale; p.res = res; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K; p.group = group;
-    int r = launch_gemm(epi, p, st);
-    if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) failed", epi, M, N, K);
-    return CR_OK;
+    return ctx_gemm(c, epi, p, st);
 }
 
 static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) {
@@ -54,7 +52,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
 
     // embeddings (modeling_intern_vit.py:167-179); bicubic pos-emb resize is the identity at 448x448
     CR_TRY(launch_im2col14(px, col, T, st));
-    CR_TRY(gemm(EPI_PATCH, col, KPAD, patch_w, KPAD, x, C1, patch_b, nullptr, pos, C1, T * 1024, C1, KPAD, 1024, st));
+    CR_TRY(gemm(c, EPI_PATCH, col, KPAD, patch_w, KPAD, x, C1, patch_b, nullptr, pos, C1, T * 1024, C1, KPAD, 1024, st));
     CR_TRY(launch_cls_rows(cls, pos, x, T, C1, TOK, st));
 
     for (int l = 0; l < c->d.vit_layers; l++) {
@@ -73,7 +71,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         np.in = x; np.ld_in = C1; np.out = h; np.ld_out = C1; np.rows = M; np.eps = c->d.vit_ln_eps;
         np.gamma = n1w; np.beta = n1b;
         CR_TRY(launch_layernorm(np, C1, 0, st));
-        CR_TRY(gemm(EPI_STORE, h, C1, qkvw, C1, qkv, C3, qkvb, nullptr, nullptr, 0, M, C3, C1, 0, st));
+        CR_TRY(gemm(c, EPI_STORE, h, C1, qkvw, C1, qkv, C3, qkvb, nullptr, nullptr, 0, M, C3, C1, 0, st));
 
         AttnParams ap{};
         ap.Q = qkv; ap.K = qkv + C1; ap.V = qkv + 2 * C1; ap.O = h;
@@ -82,12 +80,12 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         ap.B = T; ap.H = 16; ap.Sq = TOK; ap.Sk = TOK; ap.kv_group = 1; ap.q_pos0 = 0;
         ap.q_prescale = 0.125f; ap.s_div = 1.0f;
         if (launch_flash_attn(ap, 64, false, st) != CR_OK) return cr_fail(CR_ERR_HIP, "vit attention launch failed");
-        CR_TRY(gemm(EPI_LS_RES, h, C1, pw, C1, x, C1, pb, ls1, x, C1, M, C1, C1, 0, st));
+        CR_TRY(gemm(c, EPI_LS_RES, h, C1, pw, C1, x, C1, pb, ls1, x, C1, M, C1, C1, 0, st));
 
         np.gamma = n2w; np.beta = n2b;
         CR_TRY(launch_layernorm(np, C1, 0, st));
-        CR_TRY(gemm(EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
-        CR_TRY(gemm(EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
+        CR_TRY(gemm(c, EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
+        CR_TRY(gemm(c, EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
     }
     return CR_OK;
 }
@@ -109,8 +107,8 @@ static int project_chunk(cr_ctx* c, const bf16* vit_out, int T, bf16* out, hipSt
     NormParams np{};
     np.in = vit_out; np.out = a; np.ld_out = 4096; np.rows = M; np.eps = 1e-5f; np.gamma = lw; np.beta = lb;
     CR_TRY(launch_layernorm(np, 4096, 1, st));     // drop CLS + pixel_shuffle folded into the load
-    CR_TRY(gemm(EPI_GELU, a, 4096, w1, 4096, b, 4096, b1, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
-    CR_TRY(gemm(EPI_STORE, b, 4096, w3, 4096, out, 4096, b3, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
+    CR_TRY(gemm(c, EPI_GELU, a, 4096, w1, 4096, b, 4096, b1, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
+    CR_TRY(gemm(c, EPI_STORE, b, 4096, w3, 4096, out, 4096, b3, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
     return CR_OK;
 }
 

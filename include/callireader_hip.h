@@ -117,6 +117,14 @@ int cr_llm_prefill(cr_ctx* ctx, cr_kv* kv, int seq, const void* embeds, int S, f
 int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int64_t* force_tokens, float penalty,
                   float* logits, void* stream);
 
+/* ---- measurement ------------------------------------------------------------------------------- */
+/* While enabled, every launch of the dense-GEMM kernel made by the stage entry points is bracketed by a pair of
+ * HIP events on the launch stream.  cr_profile_read synchronises and returns, for the compute-bound class
+ * (M >= 1024 rows) in out[0..3] = {launches, summed kernel ms, summed algorithmic FLOPs (2*M*N*K), 0} and for the
+ * weight-streaming class (M < 1024) in out[4..7] = {launches, ms, FLOPs, algorithmic bytes (W + A + C)}; then clears. */
+int cr_profile(cr_ctx* ctx, int enable);
+int cr_profile_read(cr_ctx* ctx, double* out8);
+
 /* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
 /* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32 */
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,

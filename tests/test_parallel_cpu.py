@@ -1,0 +1,69 @@
+"""World-size-2 (and 3) gloo runs of the tile sharding + all-gather used by the N > 1 path (CPU, no GPU needed)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from callireader_amd.parallel import shard_range, shard_counts, all_gather_rows, owned_pages
+
+
+def test_shard_range_is_an_even_contiguous_partition():
+    for total in [0, 1, 7, 64, 107 * 5, 1000]:
+        for world in [1, 2, 3, 8]:
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == shard_counts(total, world)
+    assert owned_pages(10, 4, 1) == [1, 5, 9]
+    assert sorted(sum((owned_pages(10, 4, r) for r in range(4)), [])) == list(range(10))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        full = torch.arange(total * 3 * 4, dtype=torch.float32).reshape(total, 3, 4).to(torch.bfloat16)
+        lo, hi = shard_range(total, world, rank)
+        got = all_gather_rows(full[lo:hi].clone(), total)
+        ok = torch.equal(got, full)
+        # an int64 tensor (VQ indices) rides the same path
+        idx = torch.arange(total, dtype=torch.int64).reshape(total, 1)
+        ok = ok and torch.equal(all_gather_rows(idx[lo:hi].clone(), total), idx)
+        q.put((rank, bool(ok), tuple(got.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,total', [(2, 8), (2, 7), (3, 10), (2, 1)])
+def test_all_gather_rows_gloo(world, total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    assert all(r[2] == (total, 3, 4) for r in res)
+
+
+def test_single_process_passthrough():
+    x = torch.randn(5, 2)
+    assert all_gather_rows(x, 5) is x
