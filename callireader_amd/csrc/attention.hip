@@ -24,7 +24,7 @@ namespace {
 template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
 template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    const int qb = SPLIT ? 0 : blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    const int split = SPLIT ? blockIdx.x : 0;
     const int kvh = head / p.kv_group;
     const int slot = p.seq_map ? p.seq_map[batch] : batch;
     const int Sk = p.sk_arr ? p.sk_arr[slot] + p.sk_add : p.Sk;
@@ -83,6 +84,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         nt = min(nt, kmax / 64 + 1);
     }
     const int qpos = p.q_pos0 + qi_c;
+    int t_begin = 0;
+    if (SPLIT) {
+        t_begin = min(split * ATTN_SPLIT_TILES, nt);
+        nt = min(nt, t_begin + ATTN_SPLIT_TILES);
+    }
 
     f32x16 oacc[DB];
 #pragma unroll
@@ -100,10 +106,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     const int v_clow = (g & 1) * 2 + (tp >> 1);
     const int v_lane_off = v_lane_row * ROWB + (tp & 1) * 8;
 
-    stage(0, 0);
+    if (t_begin < nt) stage(0, t_begin);
     __syncthreads();
-    for (int kt = 0; kt < nt; kt++) {
-        const int cur = kt & 1;
+    for (int kt = t_begin; kt < nt; kt++) {
+        const int cur = (kt - t_begin) & 1;
         if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
         const char* kbuf = smem + cur * (2 * TILE);
         const char* vbuf = kbuf + TILE;
@@ -176,6 +182,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 
     // ---- normalise and store: lane (query, half) owns d = 32db + 8g4 + 4hh + 0..3 ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (SPLIT) {
+        // partials: un-normalised O (fp32), running max and row sum; merged by attn_combine_kernel
+        if (qi < p.Sq) {
+            const int64_t row = (((int64_t)batch * p.H + head) * p.nsplit + split) * p.Sq + qi;
+            if (hh == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
+            float* po = p.part_o + row * D + 4 * hh;
+#pragma unroll
+            for (int db = 0; db < DB; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+                    *(f32x4*)(po + 32 * db + 8 * g4) = f32x4{oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]};
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     if (qi < p.Sq) {
         bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qi * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
@@ -205,7 +225,50 @@ int launch_t(const AttnParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
+// out[b][q][h][:] = sum_s exp(m_s - M) O_s / sum_s exp(m_s - M) l_s   (splits in index order: reproducible)
+template <int D>
+__global__ __launch_bounds__(D) void attn_combine_kernel(const AttnParams p) {
+    const int q = blockIdx.x, head = blockIdx.y, batch = blockIdx.z, d = threadIdx.x;
+    const int64_t base = ((int64_t)batch * p.H + head) * p.nsplit;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; s++) M = fmaxf(M, p.part_ml[((base + s) * p.Sq + q) * 2]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < p.nsplit; s++) {
+        const int64_t row = (base + s) * p.Sq + q;
+        const float w = __expf(p.part_ml[row * 2] - M);
+        L += w * p.part_ml[row * 2 + 1];
+        acc += w * p.part_o[row * D + d];
+    }
+    p.O[(int64_t)batch * p.o_bs + (int64_t)q * p.o_rs + (int64_t)head * p.o_hs + d] = f2bf(acc / L);
+}
+
+template <int D>
+int launch_split_t(const AttnParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 2 * 64 * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel<D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return CR_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((flash_attn_kernel<D, false, true>), dim3(p.nsplit, p.H, p.B), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(p.Sq, p.H, p.B), dim3(D), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
 }  // namespace
+
+size_t attn_split_ws_floats(int B, int H, int Sq, int nsplit, int head_dim) {
+    return (size_t)B * H * nsplit * Sq * (head_dim + 2);
+}
+
+int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t stream) {
+    if (p.Sq <= 0 || p.Sq > 32 || p.H <= 0 || p.B <= 0 || p.nsplit <= 0 || !p.part_ml || !p.part_o) return CR_ERR_ARG;
+    if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7)) return CR_ERR_ARG;
+    if (head_dim == 64) return launch_split_t<64>(p, stream);
+    if (head_dim == 128) return launch_split_t<128>(p, stream);
+    return CR_ERR_ARG;
+}
 
 int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream) {
     if (p.Sq <= 0 || (p.Sk <= 0 && !p.sk_arr) || p.H <= 0 || p.B <= 0 || p.kv_group <= 0) return CR_ERR_ARG;

@@ -17,6 +17,16 @@ struct AttnParams {
     const int32_t* seq_map;
     const int32_t* sk_arr;
     int sk_add;
+    // split-KV (decode): workgroup x = split of SPLIT_TILES key tiles; partial (m, l) and un-normalised O go to
+    // part_ml [B][H][nsplit][Sq][2] / part_o [B][H][nsplit][Sq][D] (fp32), merged by launch_attn_combine
+    int nsplit;
+    float* part_ml;
+    float* part_o;
 };
 
+constexpr int ATTN_SPLIT_TILES = 4;      // 256 keys per split: depends only on the row's own key count
+
 int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream);
+// decode: Sq <= 32 query rows per (batch, head), non-causal over each sequence's own keys, split over the keys
+int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t stream);
+size_t attn_split_ws_floats(int B, int H, int Sq, int nsplit, int head_dim);

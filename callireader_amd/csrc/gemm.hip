@@ -238,10 +238,14 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+bool gemm_skinny_supported(int epi, const GemmParams& p);
+int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream);
+
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return CR_ERR_ARG;
     if ((p.lda & 7) || (p.ldw & 7)) return CR_ERR_ARG;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.C & 15)) return CR_ERR_ARG;
+    if (gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE>(p, stream);
         case EPI_GELU: return launch_t<EPI_GELU>(p, stream);

@@ -1,0 +1,136 @@
+// Weight-streaming GEMM for decode:  C[M,N] = epi(X[M,K] . W[N,K]^T),  M <= 64 rows.
+//
+// HBM-bound: every W byte is read exactly once, X (M x K, <= 1.8 MB) is served from L2.  No LDS staging
+// ("GEMV / M <= 16 decode weights: load straight to VGPRs, deep unroll, late vmcnt").
+//   * one workgroup owns 16 rows of W (one v_mfma_f32_16x16x32_bf16 A-tile) over the whole K;
+//     its WAVES waves split K into contiguous slices, so N/16 * WAVES waves keep enough loads in flight
+//     to cover HBM latency (WAVES = 8 for N <= 8192, 4 above);
+//   * per k-step a lane loads 16 B of W (row n = lane&15, k = 8*(lane>>4) .. +7) and 16 B of each X tile,
+//     UNROLL k-steps of loads are issued before the first MFMA;
+//   * accumulator = C^T tile [16 n][16 m] per X tile, so the lane holds 4 consecutive n of one m;
+//   * partial tiles of the waves are summed through LDS in a fixed order (bitwise reproducible, and a row's
+//     result does not depend on how many other rows are in the batch);
+//   * epilogues: store / +residual / SwiGLU (rows [8 gate | 8 up] of one tile -> 8 outputs) / fp32 logits.
+#include "common.hpp"
+
+namespace {
+
+template <int EPI, int WAVES, int MT>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParams p) {
+    __shared__ float red[WAVES][MT][16][17];
+    constexpr int UNROLL = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int nrow = min(n0 + (lane & 15), p.N - 1);
+    const int kq = (lane >> 4) * 8;
+    const int ksteps = p.K / (32 * WAVES);            // k-steps of 32 per wave
+    const int kbase = wave * ksteps * 32;
+    const bf16* wp = p.W + (int64_t)nrow * p.ldw + kbase + kq;
+    const bf16* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) xp[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int ks = 0;
+    for (; ks + UNROLL <= ksteps; ks += UNROLL) {
+        bf16x8 w[UNROLL], x[MT][UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) w[u] = __builtin_nontemporal_load((const bf16x8*)(wp + (ks + u) * 32));
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) x[t][u] = *(const bf16x8*)(xp[t] + (ks + u) * 32);
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[t][u], acc[t], 0, 0, 0);
+    }
+    for (; ks < ksteps; ks++) {
+        const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp + ks * 32));
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const bf16x8 x = *(const bf16x8*)(xp[t] + ks * 32);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[t], 0, 0, 0);
+        }
+    }
+    // C^T tile: row (n) = (lane>>4)*4 + e, col (m) = lane&15
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[wave][t][(lane >> 4) * 4 + e][lane & 15] = acc[t][e];
+    __syncthreads();
+
+    // thread -> (m tile, n, m); sum the waves' partials in wave order
+    for (int idx = tid; idx < MT * 256; idx += WAVES * 64) {
+        const int t = idx >> 8, n = idx & 15, m = (idx >> 4) & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) s += red[w][t][n][m];
+        red[0][t][n][m] = s;       // own element only: no hazard with other threads' reads
+    }
+    __syncthreads();
+    if (EPI == EPI_SWIGLU) {
+        for (int idx = tid; idx < MT * 128; idx += WAVES * 64) {
+            const int t = idx >> 7, j = idx & 7, m = (idx >> 3) & 15;
+            const int gm = t * 16 + m, gno = n0 / 2 + j;
+            if (gm < p.M && gno < p.N / 2) {
+                const float g = rbf(red[0][t][j][m]), u = rbf(red[0][t][8 + j][m]);
+                ((bf16*)p.C)[(int64_t)gm * p.ldc + gno] = f2bf(rbf(silu(g)) * u);
+            }
+        }
+        return;
+    }
+    for (int idx = tid; idx < MT * 256; idx += WAVES * 64) {
+        const int t = idx >> 8, n = idx & 15, m = (idx >> 4) & 15;
+        const int gm = t * 16 + m, gn = n0 + n;
+        if (gm >= p.M || gn >= p.N) continue;
+        float x = rbf(red[0][t][n][m] + (p.bias ? bf2f(p.bias[gn]) : 0.f));
+        if (EPI == EPI_F32) { ((float*)p.C)[(int64_t)gm * p.ldc + gn] = x; continue; }
+        if (EPI == EPI_RES) x = bf2f(p.res[(int64_t)gm * p.ldr + gn]) + x;
+        ((bf16*)p.C)[(int64_t)gm * p.ldc + gn] = f2bf(x);
+    }
+}
+
+template <int EPI, int WAVES>
+int launch_mt(const GemmParams& p, hipStream_t stream) {
+    const int mt = (p.M + 15) / 16;
+    const dim3 grid((p.N + 15) / 16), block(WAVES * 64);
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 1>), grid, block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 2>), grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 3>), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 4>), grid, block, 0, stream, p); break;
+        default: return CR_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+template <int EPI>
+int launch_w(const GemmParams& p, hipStream_t stream) {
+    if (p.N <= 8192 && p.K % 256 == 0) return launch_mt<EPI, 8>(p, stream);
+    return launch_mt<EPI, 4>(p, stream);
+}
+
+}  // namespace
+
+bool gemm_skinny_supported(int epi, const GemmParams& p) {
+    if (p.M > 64 || p.K % 128 != 0) return false;
+    if (epi == EPI_STORE || epi == EPI_F32) return true;
+    if (epi == EPI_RES) return p.res != nullptr;
+    if (epi == EPI_SWIGLU) return p.N % 16 == 0;
+    return false;
+}
+
+int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream) {
+    switch (epi) {
+        case EPI_STORE: return launch_w<EPI_STORE>(p, stream);
+        case EPI_RES: return launch_w<EPI_RES>(p, stream);
+        case EPI_SWIGLU: return launch_w<EPI_SWIGLU>(p, stream);
+        case EPI_F32: return launch_w<EPI_F32>(p, stream);
+    }
+    return CR_ERR_ARG;
+}

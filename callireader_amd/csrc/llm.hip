@@ -213,9 +213,11 @@ int layer_weights(cr_ctx* c, int l, LayerW& w) {
 }
 
 // The decoder stack over M rows (prefill: M = S rows of one sequence; decode: M = n sequences, one row each).
-int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int pos0, const int32_t* d_seqs, hipStream_t st) {
+int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int pos0, const int32_t* d_seqs, int nsplit,
+               hipStream_t st) {
     const int ff = (int)WT(c, "derived.w13.0")->shape[0] / 2;
     Arena ar(c->ws);
+    float* part = decode ? ar.take<float>(attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD)) : nullptr;
     bf16* h = ar.take<bf16>((size_t)M * D);
     bf16* qkv = ar.take<bf16>((size_t)M * QKV);
     bf16* q = ar.take<bf16>((size_t)M * D);
@@ -247,7 +249,8 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int 
             ap.q_bs = D; ap.q_rs = HD; ap.q_hs = 4 * HD; ap.o_bs = D; ap.o_rs = HD; ap.o_hs = 4 * HD;
             ap.B = M; ap.H = NKV; ap.Sq = NH / NKV; ap.Sk = 0; ap.kv_group = 1; ap.q_pos0 = 0;
             ap.seq_map = d_seqs; ap.sk_arr = kv->d_len; ap.sk_add = 1;
-            if (launch_flash_attn(ap, HD, false, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
+            ap.nsplit = nsplit; ap.part_ml = part; ap.part_o = part + (size_t)M * NKV * nsplit * (NH / NKV) * 2;
+            if (launch_flash_attn_split(ap, HD, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
         }
         CR_TRY(gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
         CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
@@ -258,9 +261,9 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int 
     return CR_OK;
 }
 
-size_t layers_ws(cr_ctx* c, int M) {
+size_t layers_ws(cr_ctx* c, int M, int nsplit = 0) {
     const size_t ff = (size_t)WT(c, "derived.w13.0")->shape[0] / 2;
-    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + 8192;
+    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + 8192;
 }
 
 }  // namespace
@@ -384,7 +387,7 @@ int cr_llm_prefill(cr_ctx* c, cr_kv* kv, int seq, const void* embeds, int S, flo
     bf16* hl = x + (size_t)S * D;
     float* lg = (float*)(((uintptr_t)(hl + D) + 255) & ~(uintptr_t)255);
     CR_HIP(hipMemcpyAsync(x, embeds, (size_t)S * D * 2, hipMemcpyDeviceToDevice, st));
-    CR_TRY(run_layers(c, kv, x, S, false, seq, kv->len[seq], nullptr, st));
+    CR_TRY(run_layers(c, kv, x, S, false, seq, kv->len[seq], nullptr, 0, st));
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!nw || !ow) return CR_ERR_STATE;
     // only the last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)
@@ -413,7 +416,10 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = c->d.vocab;
-    const size_t lw = layers_ws(c, n);
+    int max_len = 0;
+    for (int i = 0; i < n; i++) max_len = kv->len[seqs[i]] > max_len ? kv->len[seqs[i]] : max_len;
+    const int nsplit = ((max_len + 1 + 63) / 64 + ATTN_SPLIT_TILES - 1) / ATTN_SPLIT_TILES;
+    const size_t lw = layers_ws(c, n, nsplit);
     CR_TRY(ws_ensure(c, lw + (size_t)n * D * 4 + (size_t)n * V * 4 + 4096));
     bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
     bf16* hl = x + (size_t)n * D;
@@ -423,7 +429,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!table || !nw || !ow) return CR_ERR_STATE;
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, table, force_tokens, kv->d_seqs, kv->d_gen, kv->d_ngen, kv->gen_cap, x);
-    CR_TRY(run_layers(c, kv, x, n, true, 0, 0, kv->d_seqs, st));
+    CR_TRY(run_layers(c, kv, x, n, true, 0, 0, kv->d_seqs, nsplit, st));
     CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
     CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
     if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));

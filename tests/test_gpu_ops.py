@@ -156,6 +156,49 @@ def test_gemm_ragged_n_and_f32(E):
     torch.testing.assert_close(out, rb(A.float() @ W.float().t()), rtol=RTOL, atol=2e-2)
 
 
+@pytest.mark.parametrize('M,N,K', [(1, 4096, 4096), (8, 6144, 4096), (17, 4096, 14336), (64, 12288, 1792), (3, 1003, 512), (16, 256, 128)])
+def test_gemm_skinny_decode_shapes(E, M, N, K):
+    """M <= 64 takes the weight-streaming kernel (4 or 8 K-slices per workgroup)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.03)).to(dev())
+    res = bf(_rand((M, N), g)).to(dev())
+    acc = A.float() @ W.float().t()
+    for out, ref in [(E.op_gemm(0, A, W), rb(acc)), (E.op_gemm(3, A, W, res=res), rb(res.float() + rb(acc))),
+                     (E.op_gemm(6, A, W, out_dtype=torch.float32), rb(acc))]:
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=2e-2)
+    # exact integers: fragment layout / K-slice reduction
+    Ai = torch.randint(-1, 2, (M, K), generator=g).float()
+    Wi = torch.randint(-1, 2, (N, K), generator=g).float()
+    Ai[:, 0] = (torch.arange(M) % 3 - 1).float()
+    Wi[:, 1] = (torch.arange(N) % 2).float()
+    ref = Ai @ Wi.t()
+    if float(ref.abs().max()) <= 256:
+        out = E.op_gemm(0, bf(Ai).to(dev()), bf(Wi).to(dev()))
+        torch.cuda.synchronize()
+        assert torch.equal(out.float().cpu(), ref)
+
+
+def test_gemm_skinny_swiglu_and_row_independence(E):
+    g = torch.Generator().manual_seed(31)
+    M, F, K = 9, 1024, 4096
+    A = bf(_rand((M, K), g)).to(dev())
+    w1 = bf(_rand((F, K), g, 0.03))
+    w3 = bf(_rand((F, K), g, 0.03))
+    W = torch.stack([w1.reshape(F // 8, 8, K), w3.reshape(F // 8, 8, K)], dim=1).reshape(2 * F, K).to(dev())
+    gte = rb(A.float() @ w1.float().t().to(dev()))
+    up = rb(A.float() @ w3.float().t().to(dev()))
+    out = E.op_gemm(4, A, W)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float(), rb(rb(torch.nn.functional.silu(gte)) * up), rtol=RTOL, atol=2e-2)
+    # a row's result must not depend on the batch it is decoded with (pages decode together)
+    one = E.op_gemm(4, A[4:5].contiguous(), W)
+    big = E.op_gemm(4, torch.cat([A] * 4).contiguous(), W)
+    torch.cuda.synchronize()
+    assert torch.equal(one[0], out[4]) and torch.equal(big[9 + 4], out[4])
+
+
 def test_gemm_rejects_bad_k(E):
     A = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
     W = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
