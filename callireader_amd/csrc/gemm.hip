@@ -18,80 +18,16 @@
 //     contiguous columns of a row: 16-B loads of bias/scale/residual, the
 //     reference's bf16 rounding sequence, one 16-B store (full 128-B lines).
 //   * rows beyond M / N are clamped on load and masked on store.
-#include "common.hpp"
+#include <stdlib.h>
+
+#include "gemm_epilogue.hpp"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_LD = 68;                         // fp32 words per staged row (64 + 4 pad)
 constexpr int LDS_MAIN = 2 * (BM + BN) * BK * 2;     // 65536
 constexpr int LDS_STAGE = 4 * 64 * STAGE_LD * 4;     // 69632
 constexpr int LDS_BYTES = LDS_STAGE > LDS_MAIN ? LDS_STAGE : LDS_MAIN;
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_row8(const GemmParams& p, int gm, int gn, const float* v) {
-    // v[0..7]: fp32 accumulators of row gm, columns gn..gn+7 (gn % 8 == 0, gn + 8 <= N)
-    float x[8];
-    if (p.bias) {
-        bf16x8 b = *(const bf16x8*)(p.bias + gn);
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = rbf(v[e] + bf2f(b[e]));
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = rbf(v[e]);
-    }
-    if (EPI == EPI_F32) {
-        float* c = (float*)p.C + (int64_t)gm * p.ldc + gn;
-        if ((p.ldc & 3) == 0) {
-            *(f32x4*)c = f32x4{x[0], x[1], x[2], x[3]};
-            *(f32x4*)(c + 4) = f32x4{x[4], x[5], x[6], x[7]};
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; e++) c[e] = x[e];
-        }
-        return;
-    }
-    int64_t orow = gm;
-    if (EPI == EPI_GELU) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = gelu_erf(x[e]);
-    } else if (EPI == EPI_LS_RES) {
-        bf16x8 s = *(const bf16x8*)(p.scale + gn);
-        bf16x8 r = *(const bf16x8*)(p.res + (int64_t)gm * p.ldr + gn);
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = bf2f(r[e]) + rbf(x[e] * bf2f(s[e]));
-    } else if (EPI == EPI_RES) {
-        bf16x8 r = *(const bf16x8*)(p.res + (int64_t)gm * p.ldr + gn);
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = bf2f(r[e]) + x[e];
-    } else if (EPI == EPI_PATCH) {
-        int t = gm / p.group, pi = gm - t * p.group;
-        orow = (int64_t)t * (p.group + 1) + 1 + pi;
-        bf16x8 r = *(const bf16x8*)(p.res + (int64_t)(1 + pi) * p.ldr + gn);
-#pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = x[e] + bf2f(r[e]);
-    }
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(x[e]);
-    *(bf16x8*)((bf16*)p.C + orow * p.ldc + gn) = o;
-}
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_scalar(const GemmParams& p, int gm, int gn, float v) {
-    float x = rbf(v + (p.bias ? bf2f(p.bias[gn]) : 0.0f));
-    if (EPI == EPI_F32) { ((float*)p.C)[(int64_t)gm * p.ldc + gn] = x; return; }
-    int64_t orow = gm;
-    if (EPI == EPI_GELU) x = gelu_erf(x);
-    else if (EPI == EPI_LS_RES) x = bf2f(p.res[(int64_t)gm * p.ldr + gn]) + rbf(x * bf2f(p.scale[gn]));
-    else if (EPI == EPI_RES) x = bf2f(p.res[(int64_t)gm * p.ldr + gn]) + x;
-    else if (EPI == EPI_PATCH) {
-        int t = gm / p.group, pi = gm - t * p.group;
-        orow = (int64_t)t * (p.group + 1) + 1 + pi;
-        x = x + bf2f(p.res[(int64_t)(1 + pi) * p.ldr + gn]);
-    }
-    ((bf16*)p.C)[orow * p.ldc + gn] = f2bf(x);
-}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
@@ -183,44 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the stage is wave-private
     __builtin_amdgcn_wave_barrier();
 
-    if (EPI == EPI_SWIGLU) {
-        // staged columns: [8 gate | 8 up] x 4 per 64-wide row -> 32 outputs per row
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int row = it * 16 + (lane >> 2);
-            const int oc = lane & 3;
-            const int gm = m0 + wm * 64 + row;
-            const int gno = (n0 + wn * 64) / 2 + oc * 8;
-            if (gm < p.M && gno + 8 <= p.N / 2) {
-                const float* sp = st + row * STAGE_LD + oc * 16;
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float g = rbf(sp[e]), u = rbf(sp[8 + e]);
-                    o[e] = f2bf(rbf(silu(g)) * u);
-                }
-                *(bf16x8*)((bf16*)p.C + (int64_t)gm * p.ldc + gno) = o;
-            }
-        }
-        return;
-    }
-    const bool vec_ok = ((p.ldc & 7) == 0) || (EPI == EPI_F32);
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int row = it * 8 + (lane >> 3);
-        const int c8 = (lane & 7) * 8;
-        const int gm = m0 + wm * 64 + row;
-        const int gn = n0 + wn * 64 + c8;
-        if (gm >= p.M || gn >= p.N) continue;
-        const float* sp = st + row * STAGE_LD + c8;
-        if (gn + 8 <= p.N && vec_ok) {
-            f32x4 v0 = *(const f32x4*)sp, v1 = *(const f32x4*)(sp + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            epilogue_row8<EPI>(p, gm, gn, v);
-        } else {
-            for (int e = 0; e < 8 && gn + e < p.N; e++) epilogue_scalar<EPI>(p, gm, gn + e, sp[e]);
-        }
-    }
+    epilogue_subtile<EPI>(p, st, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <int EPI>
@@ -238,6 +137,8 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+bool gemm256_supported(int epi, const GemmParams& p);
+int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream);
 bool gemm_skinny_supported(int epi, const GemmParams& p);
 int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream);
 
@@ -245,7 +146,9 @@ int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return CR_ERR_ARG;
     if ((p.lda & 7) || (p.ldw & 7)) return CR_ERR_ARG;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.C & 15)) return CR_ERR_ARG;
-    if (gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
+    static const int force = [] { const char* e = getenv("CR_GEMM_FORCE"); return e ? atoi(e) : 0; }();   // tuning aid: 128 | 256
+    if (force != 128 && force != 256 && gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
+    if (force != 128 && (force == 256 ? (p.K % 128) == 0 : gemm256_supported(epi, p))) return launch_gemm256(epi, p, stream);   // large M: 256x256 8-phase kernel
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE>(p, stream);
         case EPI_GELU: return launch_t<EPI_GELU>(p, stream);

@@ -10,7 +10,7 @@
 #include "misc.hpp"
 #include "norm.hpp"
 
-static constexpr int VIT_CHUNK = 64;
+static constexpr int VIT_CHUNK = 63;   // 63*1025 rows = 253 row-tiles of 256: x4 column tiles = 3.95 rounds of 256 CUs
 static constexpr int C1 = 1024, C3 = 3072, FF = 4096, TOK = 1025, KPAD = 640;
 
 int vit_finalize(cr_ctx* c, hipStream_t st) {
