@@ -7,6 +7,9 @@ if the shared object is missing or does not export the ABI, import fails loudly.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: PyTorch-ROCm bundles its own libamdhip64; loading ours before it would start a
+#                              second HIP runtime in the process ("no ROCm-capable device is detected")
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcallireader_hip.so')
 
 CR_OK = 0

@@ -38,6 +38,7 @@ class InternVLChatModel:
         self.ps_version = 'v2'
         self.select_layer = -1
         self.img_context_token_id = None                                    # :192
+        self.aligned_token_id = ALIGNED_TOKEN_ID                            # 92537, hard-coded at :1100
         self.conv_template = get_conv_template(self.template)
         self.system_message = self.conv_template.system_message            # :194
         self.max_tokens = max_tokens
@@ -179,9 +180,9 @@ class InternVLChatModel:
             ids = input_ids.reshape(-1)
             assert (ids == self.img_context_token_id).sum() != 0            # :1095
             if reference_embeds is not None:
-                assert (ids == ALIGNED_TOKEN_ID).sum() != 0                 # :1101
+                assert (ids == self.aligned_token_id).sum() != 0            # :1101
             input_embeds = self.engine.embed_splice(ids, vit_embeds, reference_embeds,
-                                                    img_id=self.img_context_token_id, ref_id=ALIGNED_TOKEN_ID)
+                                                    img_id=self.img_context_token_id, ref_id=self.aligned_token_id)
         else:
             input_embeds = self.engine.embed_splice(input_ids.reshape(-1))  # :1107
         max_new, eos = self._gen_args(generate_kwargs)
