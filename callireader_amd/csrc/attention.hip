@@ -17,14 +17,28 @@
 //   LLM  (modeling_internlm2.py:393-410): scores rounded to bf16, divided by sqrt(d) -> bf16,
 //        causal mask, fp32 softmax, probabilities cast to bf16 before .V (we cast the
 //        un-normalised exp and divide the fp32 accumulator by the fp32 row sum at the end).
+#include <type_traits>
+
 #include "attention.hpp"
 
 namespace {
 
+constexpr float LOG2E = 1.4426950408889634f;
+
+// (a, b) -> bf16-rounded (RNE) values as floats: the cast of the pair compiles to one v_cvt_pk_bf16_f32; unpacking
+// through integer ops keeps LLVM from folding the rounding away.  Deliberately NOT inline asm: as the first reader
+// of MFMA results an asm statement gets no MFMA->VALU wait states from hipcc (NaNs observed).
+__device__ __forceinline__ void round_pair_bf16(float a, float b, float& ra, float& rb2) {
+    const bf16x2 v = {(bf16)a, (bf16)b};
+    const unsigned pk = __builtin_bit_cast(unsigned, v);
+    ra = __uint_as_float(pk << 16);
+    rb2 = __uint_as_float(pk & 0xffff0000u);
+}
+
 template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
 template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
 
-template <int D, bool CAUSAL, bool SPLIT = false>
+template <int D, bool CAUSAL, bool SPLIT = false, bool DIV = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
@@ -84,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         nt = min(nt, kmax / 64 + 1);
     }
     const int qpos = p.q_pos0 + qi_c;
+    const float inv_div = 1.0f / p.s_div;     // reference divides by sqrt(d); x * (1/d) differs from x / d by <= 1 fp32 ulp before the bf16 rounding
     int t_begin = 0;
     if (SPLIT) {
         t_begin = min(split * ATTN_SPLIT_TILES, nt);
@@ -113,6 +128,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
         const char* kbuf = smem + cur * (2 * TILE);
         const char* vbuf = kbuf + TILE;
+        // decode: a wave whose 32 query rows are all padding only helps staging (wave-uniform branch)
+        if (!SPLIT || wave * 32 < p.Sq) {
 
         // ---- S^T = K . Q^T for two 32-key blocks ----
         f32x16 sacc[2];
@@ -127,29 +144,38 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             }
         }
         // ---- scores: reference rounding, masking, online softmax (query = lane) ----
+        // bf16 rounding of a pair with one v_cvt_pk_bf16_f32 (RNE) + two unpack ops; masking only on tiles that need it
+        const bool need_mask = (kt * 64 + 64 > Sk) || (CAUSAL && kt * 64 + 63 > p.q_pos0 + qb * 128 + wave * 32);
         float mloc = -INFINITY;
+        auto score_pass = [&](auto masked) {
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++)
+            for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                float s = rbf(sacc[kb][e]);
-                if (p.s_div != 1.0f) s = rbf(s / p.s_div);
-                const int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const bool ok = key < Sk && (!CAUSAL || key <= qpos);
-                s = ok ? s : -INFINITY;
-                sacc[kb][e] = s;
-                mloc = fmaxf(mloc, s);
-            }
+                for (int e = 0; e < 16; e += 2) {
+                    float s0, s1;
+                    round_pair_bf16(sacc[kb][e], sacc[kb][e + 1], s0, s1);
+                    if (DIV) round_pair_bf16(s0 * inv_div, s1 * inv_div, s0, s1);
+                    if (decltype(masked)::value) {
+                        const int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        s0 = (key < Sk && (!CAUSAL || key <= qpos)) ? s0 : -INFINITY;
+                        s1 = (key + 1 < Sk && (!CAUSAL || key + 1 <= qpos)) ? s1 : -INFINITY;
+                    }
+                    sacc[kb][e] = s0; sacc[kb][e + 1] = s1;
+                    mloc = fmaxf(mloc, fmaxf(s0, s1));
+                }
+        };
+        if (need_mask) score_pass(std::true_type{}); else score_pass(std::false_type{});   // wave-uniform
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __expf(m_run - m_new);
+        const float m2 = m_new * LOG2E;                       // exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp_f32
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // raw v_exp_f32: arguments are <= 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const float pe = __expf(sacc[kb][e] - m_new);
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], LOG2E, -m2));
                 sacc[kb][e] = pe;
                 psum += pe;
             }
@@ -177,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
                 }
             }
+        }
         __syncthreads();
     }
 
@@ -211,18 +238,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     }
 }
 
-template <int D, bool CAUSAL>
-int launch_t(const AttnParams& p, hipStream_t stream) {
+template <int D, bool CAUSAL, bool DIV>
+int launch_d(const AttnParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 64 * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)flash_attn_kernel<D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel<D, CAUSAL, false, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CR_ERR_HIP;
         attr_set = true;
     }
     dim3 grid((p.Sq + 127) / 128, p.H, p.B);
-    hipLaunchKernelGGL((flash_attn_kernel<D, CAUSAL>), grid, dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((flash_attn_kernel<D, CAUSAL, false, DIV>), grid, dim3(256), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+template <int D, bool CAUSAL>
+int launch_t(const AttnParams& p, hipStream_t stream) {
+    return p.s_div != 1.0f ? launch_d<D, CAUSAL, true>(p, stream) : launch_d<D, CAUSAL, false>(p, stream);
 }
 
 // out[b][q][h][:] = sum_s exp(m_s - M) O_s / sum_s exp(m_s - M) l_s   (splits in index order: reproducible)
@@ -242,16 +274,16 @@ __global__ __launch_bounds__(D) void attn_combine_kernel(const AttnParams p) {
     p.O[(int64_t)batch * p.o_bs + (int64_t)q * p.o_rs + (int64_t)head * p.o_hs + d] = f2bf(acc / L);
 }
 
-template <int D>
-int launch_split_t(const AttnParams& p, hipStream_t stream) {
+template <int D, bool DIV>
+int launch_split_d(const AttnParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 64 * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)flash_attn_kernel<D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel<D, false, true, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CR_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL((flash_attn_kernel<D, false, true>), dim3(p.nsplit, p.H, p.B), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((flash_attn_kernel<D, false, true, DIV>), dim3(p.nsplit, p.H, p.B), dim3(256), LDS, stream, p);
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(p.Sq, p.H, p.B), dim3(D), 0, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
@@ -265,8 +297,9 @@ size_t attn_split_ws_floats(int B, int H, int Sq, int nsplit, int head_dim) {
 int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t stream) {
     if (p.Sq <= 0 || p.Sq > 32 || p.H <= 0 || p.B <= 0 || p.nsplit <= 0 || !p.part_ml || !p.part_o) return CR_ERR_ARG;
     if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7)) return CR_ERR_ARG;
-    if (head_dim == 64) return launch_split_t<64>(p, stream);
-    if (head_dim == 128) return launch_split_t<128>(p, stream);
+    const bool dv = p.s_div != 1.0f;
+    if (head_dim == 64) return dv ? launch_split_d<64, true>(p, stream) : launch_split_d<64, false>(p, stream);
+    if (head_dim == 128) return dv ? launch_split_d<128, true>(p, stream) : launch_split_d<128, false>(p, stream);
     return CR_ERR_ARG;
 }
 
