@@ -38,8 +38,14 @@ def all_gather_rows(local, total, group=None):
     if local.shape[0] != mx:
         send = torch.zeros((mx,) + tuple(tail), dtype=local.dtype, device=local.device)
         send[:local.shape[0]] = local
-    recv = torch.empty((world * mx,) + tuple(tail), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if send.is_cuda and dist.get_backend(group) == 'gloo':
+        # functional fallback for single-GPU test boxes (ranks sharing one device): gloo moves host buffers
+        host = torch.empty((world * mx,) + tuple(tail), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, send.contiguous().cpu(), group=group)
+        recv = host.to(local.device)
+    else:
+        recv = torch.empty((world * mx,) + tuple(tail), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     if all(c == mx for c in counts):
         return recv
     return torch.cat([recv[r * mx:r * mx + c] for r, c in enumerate(counts)], dim=0)
