@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Run under torch.distributed.run: the tile-sharded + all-gather + round-robin page flow must give, for every page,
+exactly the ids a single process produces.  Reduced depth (1 layer each, full width).  Backend: CR_DIST_BACKEND
+(gloo lets both ranks share GPU 0 on a single-GPU box; nccl on a real multi-GPU node)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+
+from callireader_amd.config import ModelDims
+from callireader_amd import synthetic
+from callireader_amd.modeling_internvl_chat import InternVLChatModel
+from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+backend = os.environ.get('CR_DIST_BACKEND', 'nccl')
+dev_idx = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
+torch.cuda.set_device(dev_idx)
+dist.init_process_group(backend)
+
+IMG, REF = 8990, 8991
+PT, CT, NEW = 2, 5, 6                       # page tiles, char tiles per page (deliberately not divisible by world), new tokens
+n_pages = 3
+dims = ModelDims.reduced(vit_layers=1, llm_layers=1, rs_depth=1, vocab=9000)
+sd = synthetic.make_state_dict(dims, seed=0)
+m = InternVLChatModel.from_state_dict(sd, dims, device=dev_idx, max_tokens=1024, max_pages=n_pages)
+m.img_context_token_id, m.aligned_token_id = IMG, REF
+page_px = synthetic.make_pixels(n_pages * PT, seed=5)
+char_px = synthetic.make_pixels(n_pages * CT, seed=6)
+ids = [torch.cat([torch.arange(50 + p, 60 + p), torch.full((PT * 256,), IMG), torch.full((CT * 3,), REF), torch.arange(7)]) for p in range(n_pages)]
+
+
+def run(pages, vit_all, pseudo_all):
+    embeds = [m.engine.embed_splice(ids[p], vit_all[p * PT:(p + 1) * PT], pseudo_all[p * CT:(p + 1) * CT], img_id=IMG, ref_id=REF) for p in pages]
+    return m.generate_pages(embeds, max_new_tokens=NEW, eos_token_id=None)
+
+
+lo, hi = shard_range(n_pages * PT, world, rank)
+clo, chi = shard_range(n_pages * CT, world, rank)
+vit_all = all_gather_rows(m.extract_feature(page_px[lo:hi].cuda()), n_pages * PT)
+pseudo, _ = m.align_tiles(char_px[clo:chi].cuda())
+pseudo_all = all_gather_rows(pseudo.reshape(-1, 3, dims.llm_hidden), n_pages * CT)
+mine = owned_pages(n_pages, world, rank)
+outs = dict(zip(mine, run(mine, vit_all, pseudo_all)))
+gathered = [None] * world
+dist.all_gather_object(gathered, outs)
+if rank == 0:
+    merged = {}
+    for g in gathered:
+        merged.update(g)
+    v1 = m.extract_feature(page_px.cuda())
+    p1, _ = m.align_tiles(char_px.cuda())
+    single = run(list(range(n_pages)), v1, p1.reshape(-1, 3, dims.llm_hidden))
+    ok = all(merged[p] == single[p] for p in range(n_pages)) and torch.equal(v1, vit_all)
+    print('DIST_CHECK', 'OK' if ok else 'MISMATCH', merged, single, flush=True)
+dist.barrier()
+dist.destroy_process_group()
