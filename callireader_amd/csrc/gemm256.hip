@@ -275,7 +275,14 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 bool gemm256_supported(int epi, const GemmParams& p) {
-    return p.M >= 2048 && p.N >= 512 && (p.K % 128) == 0;
+    if (p.M < 2048 || p.N < 512 || (p.K % 128) != 0) return false;
+    // wave-quantisation model (calibrated on the measured shapes): a round of 256x256 tiles on
+    // 256 CUs costs 1, a round of 512 co-resident 128x128 tiles 0.55; pick the kernel with the cheaper schedule
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const double c256 = (double)((t256 + 255) / 256);
+    const double c128 = 0.55 * (double)((t128 + 511) / 512);
+    return c256 <= c128;
 }
 
 int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream) {

@@ -15,57 +15,72 @@
 
 namespace {
 
-template <int EPI, int WAVES, int MT>
+template <int EPI, int WAVES, int MT, int RT = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParams p) {
-    __shared__ float red[WAVES][MT][16][17];
+    // RT = 16-row weight tiles per wave: X fragments are loaded once per RT tiles (X re-reads through L2 are the
+    // bottleneck once M > 16), used where N is large enough to still fill the chip
+    __shared__ float red[WAVES][RT * MT][16][17];
     constexpr int UNROLL = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * 16;
-    const int nrow = min(n0 + (lane & 15), p.N - 1);
+    const int n0 = blockIdx.x * 16 * RT;
     const int kq = (lane >> 4) * 8;
     const int ksteps = p.K / (32 * WAVES);            // k-steps of 32 per wave
     const int kbase = wave * ksteps * 32;
-    const bf16* wp = p.W + (int64_t)nrow * p.ldw + kbase + kq;
+    const bf16* wp[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) wp[r] = p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq;
     const bf16* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) xp[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq;
 
-    f32x4 acc[MT];
+    constexpr int UR = RT == 1 ? UNROLL : UNROLL / 2;
+    f32x4 acc[RT][MT];
 #pragma unroll
-    for (int t = 0; t < MT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int ks = 0;
-    for (; ks + UNROLL <= ksteps; ks += UNROLL) {
-        bf16x8 w[UNROLL], x[MT][UNROLL];
+    for (; ks + UR <= ksteps; ks += UR) {
+        bf16x8 w[RT][UR], x[MT][UR];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) w[u] = __builtin_nontemporal_load((const bf16x8*)(wp + (ks + u) * 32));
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+            for (int u = 0; u < UR; u++) w[r][u] = __builtin_nontemporal_load((const bf16x8*)(wp[r] + (ks + u) * 32));
 #pragma unroll
         for (int t = 0; t < MT; t++)
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) x[t][u] = *(const bf16x8*)(xp[t] + (ks + u) * 32);
+            for (int u = 0; u < UR; u++) x[t][u] = *(const bf16x8*)(xp[t] + (ks + u) * 32);
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++)
+        for (int u = 0; u < UR; u++)
 #pragma unroll
-            for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[t][u], acc[t], 0, 0, 0);
+            for (int r = 0; r < RT; r++)
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[r][u], x[t][u], acc[r][t], 0, 0, 0);
     }
     for (; ks < ksteps; ks++) {
-        const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp + ks * 32));
+        bf16x8 x[MT];
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const bf16x8 x = *(const bf16x8*)(xp[t] + ks * 32);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[t], 0, 0, 0);
+        for (int t = 0; t < MT; t++) x[t] = *(const bf16x8*)(xp[t] + ks * 32);
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp[r] + ks * 32));
+#pragma unroll
+            for (int t = 0; t < MT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x[t], acc[r][t], 0, 0, 0);
         }
     }
-    // C^T tile: row (n) = (lane>>4)*4 + e, col (m) = lane&15
+    // C^T tile: row (n) = (lane>>4)*4 + e, col (m) = lane&15; staged tile index = r * MT + t
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int r = 0; r < RT; r++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) red[wave][t][(lane >> 4) * 4 + e][lane & 15] = acc[t][e];
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) red[wave][r * MT + t][(lane >> 4) * 4 + e][lane & 15] = acc[r][t][e];
     __syncthreads();
 
     // thread -> (m tile, n, m); sum the waves' partials in wave order
-    for (int idx = tid; idx < MT * 256; idx += WAVES * 64) {
+    for (int idx = tid; idx < RT * MT * 256; idx += WAVES * 64) {
         const int t = idx >> 8, n = idx & 15, m = (idx >> 4) & 15;
         float s = 0.f;
 #pragma unroll
@@ -74,9 +89,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
     }
     __syncthreads();
     if (EPI == EPI_SWIGLU) {
-        for (int idx = tid; idx < MT * 128; idx += WAVES * 64) {
-            const int t = idx >> 7, j = idx & 7, m = (idx >> 3) & 15;
-            const int gm = t * 16 + m, gno = n0 / 2 + j;
+        for (int idx = tid; idx < RT * MT * 128; idx += WAVES * 64) {
+            const int q = idx >> 7, j = idx & 7, m = (idx >> 3) & 15;
+            const int t = q;
+            const int gm = (q % MT) * 16 + m, gno = (n0 + (q / MT) * 16) / 2 + j;
             if (gm < p.M && gno < p.N / 2) {
                 const float g = rbf(red[0][t][j][m]), u = rbf(red[0][t][8 + j][m]);
                 ((bf16*)p.C)[(int64_t)gm * p.ldc + gno] = f2bf(rbf(silu(g)) * u);
@@ -84,9 +100,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         }
         return;
     }
-    for (int idx = tid; idx < MT * 256; idx += WAVES * 64) {
+    for (int idx = tid; idx < RT * MT * 256; idx += WAVES * 64) {
         const int t = idx >> 8, n = idx & 15, m = (idx >> 4) & 15;
-        const int gm = t * 16 + m, gn = n0 + n;
+        const int gm = (t % MT) * 16 + m, gn = n0 + (t / MT) * 16 + n;
         if (gm >= p.M || gn >= p.N) continue;
         float x = rbf(red[0][t][n][m] + (p.bias ? bf2f(p.bias[gn]) : 0.f));
         if (EPI == EPI_F32) { ((float*)p.C)[(int64_t)gm * p.ldc + gn] = x; continue; }
@@ -95,15 +111,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
     }
 }
 
-template <int EPI, int WAVES>
+template <int EPI, int WAVES, int RT>
 int launch_mt(const GemmParams& p, hipStream_t stream) {
     const int mt = (p.M + 15) / 16;
-    const dim3 grid((p.N + 15) / 16), block(WAVES * 64);
+    const dim3 grid((p.N + 16 * RT - 1) / (16 * RT)), block(WAVES * 64);
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 1>), grid, block, 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 2>), grid, block, 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 3>), grid, block, 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 4>), grid, block, 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 1, RT>), grid, block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 2, RT>), grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 3, RT>), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 4, RT>), grid, block, 0, stream, p); break;
         default: return CR_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
@@ -111,8 +127,9 @@ int launch_mt(const GemmParams& p, hipStream_t stream) {
 
 template <int EPI>
 int launch_w(const GemmParams& p, hipStream_t stream) {
-    if (p.N <= 8192 && p.K % 256 == 0) return launch_mt<EPI, 8>(p, stream);
-    return launch_mt<EPI, 4>(p, stream);
+    if (p.N <= 8192 && p.K % 256 == 0) return launch_mt<EPI, 8, 1>(p, stream);
+    if (p.N >= 16384 && p.M > 16) return launch_mt<EPI, 4, 2>(p, stream);      // two row tiles per wave: half the X re-reads
+    return launch_mt<EPI, 4, 1>(p, stream);
 }
 
 }  // namespace
