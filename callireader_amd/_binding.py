@@ -46,6 +46,7 @@ SIGNATURES = {
     'cr_kv_reset': (i32, [vp, i32]),
     'cr_kv_generated': (i32, [vp, i32, C.POINTER(i64), i32, vp]),
     'cr_llm_prefill': (i32, [vp, vp, i32, vp, i32, f32, vp, vp]),
+    'cr_llm_prefill_batch': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, C.POINTER(C.c_int32), f32, vp, vp]),
     'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, f32, vp, vp]),
     'cr_profile': (i32, [vp, i32]),
     'cr_profile_read': (i32, [vp, C.POINTER(C.c_double)]),

@@ -101,12 +101,12 @@ __global__ __launch_bounds__(128) void rope_split_kernel(const bf16* __restrict_
                                                          const bf16* __restrict__ sinT, bf16* __restrict__ q_out,
                                                          bf16* __restrict__ kc, bf16* __restrict__ vc, int pos0, int seq0,
                                                          const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
-                                                         int max_tokens) {
+                                                         const int32_t* __restrict__ row_pos, int max_tokens) {
     const int row = blockIdx.x, grp = blockIdx.y;
     const int slot = threadIdx.x >> 4, c = threadIdx.x & 15;
     if (slot >= 6) return;
     const int seq = seqs ? seqs[row] : seq0;
-    const int pos = lens ? lens[seq] : pos0 + row;
+    const int pos = row_pos ? row_pos[row] : (lens ? lens[seq] : pos0 + row);
     const bf16* src = qkv + (int64_t)row * QKV + (grp * 6 + slot) * HD;
     const bf16x8 x = *(const bf16x8*)(src + c * 8);
     bf16x8 y;
@@ -212,9 +212,11 @@ int layer_weights(cr_ctx* c, int l, LayerW& w) {
     return (w.an && w.fn && w.wqkv && w.wo && w.w13 && w.w2) ? CR_OK : CR_ERR_STATE;
 }
 
-// The decoder stack over M rows (prefill: M = S rows of one sequence; decode: M = n sequences, one row each).
-int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int pos0, const int32_t* d_seqs, int nsplit,
-               hipStream_t st) {
+struct Segment { int seq, row0, S, pos0; };     // a page's rows inside a batched prefill
+
+// The decoder stack over M rows (prefill: M = all prompt rows of the pages in `segs`; decode: M = n sequences, one row each).
+int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vector<Segment>& segs, const int32_t* d_row_seq,
+               const int32_t* d_row_pos, const int32_t* d_seqs, int nsplit, hipStream_t st) {
     const int ff = (int)WT(c, "derived.w13.0")->shape[0] / 2;
     Arena ar(c->ws);
     float* part = decode ? ar.take<float>(attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD)) : nullptr;
@@ -233,17 +235,21 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, int seq0, int 
         bf16* vc = kv->v + l * per_layer;
         CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
         CR_TRY(gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
-        hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, pos0, seq0,
-                           decode ? d_seqs : nullptr, decode ? kv->d_len : nullptr, kv->max_tokens);
+        hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
+                           decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens);
         AttnParams ap{};
         ap.K = kc; ap.V = vc; ap.Q = q; ap.O = ao;
         ap.k_bs = ap.v_bs = (int64_t)NKV * kv->max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)kv->max_tokens * HD;
         ap.q_prescale = 1.0f; ap.s_div = 11.313708498984761f;      // math.sqrt(128)
         if (!decode) {
             ap.q_bs = 0; ap.q_rs = D; ap.q_hs = HD; ap.o_bs = 0; ap.o_rs = D; ap.o_hs = HD;
-            ap.B = 1; ap.H = NH; ap.Sq = M; ap.Sk = pos0 + M; ap.kv_group = NH / NKV; ap.q_pos0 = pos0;
-            ap.K = kc + (int64_t)seq0 * ap.k_bs; ap.V = vc + (int64_t)seq0 * ap.v_bs;
-            if (launch_flash_attn(ap, HD, true, st) != CR_OK) return cr_fail(CR_ERR_HIP, "prefill attention launch failed");
+            ap.B = 1; ap.H = NH; ap.kv_group = NH / NKV;
+            for (const Segment& sg : segs) {            // causal attention is per page; the linear layers see all pages at once
+                ap.Q = q + (size_t)sg.row0 * D; ap.O = ao + (size_t)sg.row0 * D;
+                ap.Sq = sg.S; ap.Sk = sg.pos0 + sg.S; ap.q_pos0 = sg.pos0;
+                ap.K = kc + (int64_t)sg.seq * ap.k_bs; ap.V = vc + (int64_t)sg.seq * ap.v_bs;
+                if (launch_flash_attn(ap, HD, true, st) != CR_OK) return cr_fail(CR_ERR_HIP, "prefill attention launch failed");
+            }
         } else {
             // rows = the 4 query heads of one KV group, all at the same position: no mask needed
             ap.q_bs = D; ap.q_rs = HD; ap.q_hs = 4 * HD; ap.o_bs = D; ap.o_rs = HD; ap.o_hs = 4 * HD;
@@ -374,32 +380,62 @@ int cr_kv_generated(cr_kv* kv, int seq, int64_t* out_host, int max, void* stream
     return n;
 }
 
-int cr_llm_prefill(cr_ctx* c, cr_kv* kv, int seq, const void* embeds, int S, float penalty, float* last_logits, void* stream) {
-    if (!c || !kv || !embeds || S <= 0 || seq < 0 || seq >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_prefill: bad argument");
-    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_llm_prefill: call cr_finalize first");
-    if (kv->len[seq] + S > kv->max_tokens) return cr_fail(CR_ERR_ARG, "cr_llm_prefill: %d + %d tokens exceed the cache (%d)", kv->len[seq], S, kv->max_tokens);
+int cr_llm_prefill_batch(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const void* embeds, const int32_t* lens, float penalty,
+                         float* last_logits, void* stream) {
+    if (!c || !kv || !seqs || !lens || !embeds || n <= 0 || n > kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_prefill_batch: bad argument");
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_llm_prefill_batch: call cr_finalize first");
+    std::vector<Segment> segs;
+    int M = 0;
+    for (int i = 0; i < n; i++) {
+        const int s = seqs[i];
+        if (s < 0 || s >= kv->n_seqs || lens[i] <= 0) return cr_fail(CR_ERR_ARG, "cr_llm_prefill_batch: bad sequence %d / length %d", s, lens[i]);
+        for (int j = 0; j < i; j++) if (seqs[j] == s) return cr_fail(CR_ERR_ARG, "cr_llm_prefill_batch: sequence %d listed twice", s);
+        if (kv->len[s] + lens[i] > kv->max_tokens)
+            return cr_fail(CR_ERR_ARG, "cr_llm_prefill: %d + %d tokens exceed the cache (%d)", kv->len[s], lens[i], kv->max_tokens);
+        segs.push_back({s, M, lens[i], kv->len[s]});
+        M += lens[i];
+    }
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = c->d.vocab;
-    const size_t lw = layers_ws(c, S);
-    CR_TRY(ws_ensure(c, lw + (size_t)S * D * 2 + (size_t)D * 2 + (size_t)V * 4 + 4096));
+    const size_t lw = layers_ws(c, M);
+    CR_TRY(ws_ensure(c, lw + (size_t)M * D * 2 + (size_t)n * D * 2 + (size_t)n * V * 4 + (size_t)M * 8 + 8192));
     bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
-    bf16* hl = x + (size_t)S * D;
-    float* lg = (float*)(((uintptr_t)(hl + D) + 255) & ~(uintptr_t)255);
-    CR_HIP(hipMemcpyAsync(x, embeds, (size_t)S * D * 2, hipMemcpyDeviceToDevice, st));
-    CR_TRY(run_layers(c, kv, x, S, false, seq, kv->len[seq], nullptr, 0, st));
+    bf16* hl = x + (size_t)M * D;
+    float* lg = (float*)(((uintptr_t)(hl + (size_t)n * D) + 255) & ~(uintptr_t)255);
+    int32_t* d_row_seq = (int32_t*)(((uintptr_t)(lg + (size_t)n * V) + 255) & ~(uintptr_t)255);
+    int32_t* d_row_pos = d_row_seq + M;
+    {
+        std::vector<int32_t> h(2 * (size_t)M);
+        for (const Segment& sg : segs)
+            for (int r = 0; r < sg.S; r++) { h[sg.row0 + r] = sg.seq; h[(size_t)M + sg.row0 + r] = sg.pos0 + r; }
+        CR_HIP(hipMemcpyAsync(d_row_seq, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: staged before return
+    }
+    CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    CR_HIP(hipMemcpyAsync(x, embeds, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));
+    CR_TRY(run_layers(c, kv, x, M, false, segs, d_row_seq, d_row_pos, nullptr, 0, st));
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!nw || !ow) return CR_ERR_STATE;
-    // only the last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)
-    CR_TRY(rms(x + (size_t)(S - 1) * D, D, hl, nw, 1, c->d.rms_eps, st));
-    CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, 1, V, D, st));
-    if (last_logits) CR_HIP(hipMemcpyAsync(last_logits, lg, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, seq, (const int32_t*)nullptr,
-                       kv->d_gen, kv->d_ngen, kv->d_len, kv->gen_cap, S);
+    // only each page's last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)
+    for (int i = 0; i < n; i++)
+        CR_TRY(rms(x + (size_t)(segs[i].row0 + segs[i].S - 1) * D, D, hl + (size_t)i * D, nw, 1, c->d.rms_eps, st));
+    CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
+    if (last_logits) CR_HIP(hipMemcpyAsync(last_logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(pick_kernel, dim3(n), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, 0, kv->d_seqs, kv->d_gen, kv->d_ngen,
+                       kv->d_len, kv->gen_cap, 0);
     CR_HIP(hipGetLastError());
-    kv->len[seq] += S;
-    if (kv->ngen[seq] < kv->gen_cap) kv->ngen[seq] += 1;
+    for (const Segment& sg : segs) {
+        kv->len[sg.seq] += sg.S;
+        if (kv->ngen[sg.seq] < kv->gen_cap) kv->ngen[sg.seq] += 1;
+    }
+    CR_HIP(hipMemcpyAsync(kv->d_len, kv->len.data(), (size_t)kv->n_seqs * 4, hipMemcpyHostToDevice, st));
     return CR_OK;
+}
+
+int cr_llm_prefill(cr_ctx* c, cr_kv* kv, int seq, const void* embeds, int S, float penalty, float* last_logits, void* stream) {
+    if (!kv || S <= 0) return cr_fail(CR_ERR_ARG, "cr_llm_prefill: bad argument");
+    const int32_t s = seq, l = S;
+    return cr_llm_prefill_batch(c, kv, &s, 1, embeds, &l, penalty, last_logits, stream);
 }
 
 int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_t* force_tokens, float penalty, float* logits,
@@ -429,7 +465,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!table || !nw || !ow) return CR_ERR_STATE;
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, table, force_tokens, kv->d_seqs, kv->d_gen, kv->d_ngen, kv->gen_cap, x);
-    CR_TRY(run_layers(c, kv, x, n, true, 0, 0, kv->d_seqs, nsplit, st));
+    CR_TRY(run_layers(c, kv, x, n, true, {}, nullptr, nullptr, kv->d_seqs, nsplit, st));
     CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
     CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
     if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));

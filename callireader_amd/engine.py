@@ -163,6 +163,17 @@ class Engine:
         B.check(B.lib.cr_llm_prefill(self._h, kv._h, seq, _p(e), S, float(penalty), _p(logits), _stream()), 'cr_llm_prefill')
         return logits
 
+    def prefill_batch(self, kv, seqs, embeds_list, penalty=1.0, want_logits=False):
+        """Prefill several sequences in one pass (linear layers over all prompt rows, attention per sequence)."""
+        n = len(seqs)
+        es = [e.reshape(-1, self.dims.llm_hidden) for e in embeds_list]
+        lens = [e.shape[0] for e in es]
+        cat = es[0].contiguous() if n == 1 else torch.cat(es, dim=0)
+        logits = torch.empty(n, self.dims.vocab, device=self.device, dtype=torch.float32) if want_logits else None
+        B.check(B.lib.cr_llm_prefill_batch(self._h, kv._h, (C.c_int32 * n)(*seqs), n, _p(cat), (C.c_int32 * n)(*lens),
+                                           float(penalty), _p(logits), _stream()), 'cr_llm_prefill_batch')
+        return logits
+
     def decode(self, kv, seqs, penalty=1.0, force_tokens=None, want_logits=False):
         n = len(seqs)
         seq_arr = (C.c_int32 * n)(*seqs)

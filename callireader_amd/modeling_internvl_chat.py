@@ -320,7 +320,7 @@ class InternVLChatModel:
 
     # ---- page-parallel generation (new: the reference decodes one page at a time) ---------------
     def generate_pages(self, embeds_list, max_new_tokens=1024, eos_token_id=EOS_TOKEN_ID, repetition_penalty=1.0,
-                       check_every=16):
+                       check_every=16, prefill_batch=8):
         """Prefill every page, then decode all unfinished pages as ONE batch per step: the 14.7 GB of LLM weights are
         streamed once per step for all pages.  Per page the ids equal the single-page greedy result."""
         P = len(embeds_list)
@@ -330,9 +330,11 @@ class InternVLChatModel:
             self.max_pages = max(P, self.max_pages)
             self._kv = self.engine.kv_alloc(self.max_pages, self.max_tokens)
         kv = self._kv
-        for i, e in enumerate(embeds_list):
+        for i in range(P):
             kv.reset(i)
-            self.engine.prefill(kv, i, e, penalty=repetition_penalty)
+        for i0 in range(0, P, prefill_batch):                       # prompts of several pages share the linear layers' GEMMs
+            idx = list(range(i0, min(P, i0 + prefill_batch)))
+            self.engine.prefill_batch(kv, idx, [embeds_list[i] for i in idx], penalty=repetition_penalty)
         live = list(range(P))
         n = 1
         done = {}

@@ -109,6 +109,12 @@ int cr_kv_generated(cr_kv* kv, int seq, int64_t* out_host, int max, void* stream
  * embeds [S,4096]; last_logits [vocab] fp32 = raw last-row logits before the penalty (may be NULL). */
 int cr_llm_prefill(cr_ctx* ctx, cr_kv* kv, int seq, const void* embeds, int S, float penalty, float* last_logits,
                    void* stream);
+/* The same for n sequences at once: embeds is the concatenation [sum(lens), 4096] of the prompts in seqs[] order
+ * (seqs, lens: host arrays).  The linear layers run over all prompt rows together (better MFMA tile occupancy),
+ * attention stays per sequence; every sequence gets exactly the result of its own cr_llm_prefill.
+ * last_logits [n,vocab] fp32 (may be NULL). */
+int cr_llm_prefill_batch(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const void* embeds, const int32_t* lens,
+                         float penalty, float* last_logits, void* stream);
 /* One greedy step for sequences seqs[0..n) (host array): embed each sequence's last generated id (or
  * force_tokens[i], device int64, when not NULL), run the decoder against the cache, append K/V, apply the
  * penalty, argmax, append the new id.  logits [n,vocab] fp32 raw (may be NULL).  Replaces one iteration of

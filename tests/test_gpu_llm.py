@@ -136,6 +136,34 @@ def test_batched_decode_equals_single(setup):
     kv.free()
 
 
+def test_prefill_batch_equals_single(setup):
+    """Prompts of several pages share the linear layers' GEMMs; each page must get exactly its own single-prefill result
+    (the tiled GEMM kernels accumulate K in the same order for every row, attention stays per page)."""
+    eng = setup['eng']
+    embs = [prompt(300, 31), prompt(77, 32), prompt(130, 33)]
+    single_logits, single_ids = [], []
+    for e in embs:
+        kv = eng.kv_alloc(1, 512)
+        single_logits.append(eng.prefill(kv, 0, e.cuda(), want_logits=True).clone())
+        for _ in range(3):
+            eng.decode(kv, [0])
+        single_ids.append(kv.generated(0))
+        kv.free()
+    kv = eng.kv_alloc(4, 512)
+    lg = eng.prefill_batch(kv, [2, 0, 3], [e.cuda() for e in embs], want_logits=True)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(lg[i], single_logits[i])
+    for _ in range(3):
+        eng.decode(kv, [0, 2, 3])
+    assert [kv.generated(s) for s in (2, 0, 3)] == single_ids
+    assert [kv.length(s) for s in (2, 0, 3)] == [303, 80, 133] and kv.length(1) == 0
+    from callireader_amd._binding import CalliReaderError
+    with pytest.raises(CalliReaderError):
+        eng.prefill_batch(kv, [1, 1], [embs[1].cuda(), embs[1].cuda()])
+    kv.free()
+
+
 def test_kv_reset_and_limits(setup):
     from callireader_amd._binding import CalliReaderError
     eng = setup['eng']
