@@ -181,7 +181,11 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_pages / (elapsed / args.steps)
-        big_n, big_ms, big_fl = prof[0], prof[1], prof[2]
+        big_n, big_ms, big_fl, big_by = prof[0], prof[1], prof[2], prof[3]
+        traffic = None
+        tp = os.path.join(ROOT, 'profiles', 'round1', 'traffic_pmc.json')
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get('gemm_tiled_big', {}).get('traffic_bytes_per_launch')
         sm_n, sm_ms, sm_fl, sm_by = prof[4], prof[5], prof[6], prof[7]
         achieved = big_fl / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
         result = {
@@ -195,7 +199,9 @@ def main():
                        'parallelism': f'tile shards + RCCL all-gather of visual embeds, pages round-robin, dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm128_kernel (bf16 MFMA GEMM, launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill)',
                          'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_note': 'bytes per launch on the L2 fabric side (Infinity-Cache hits included), (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this bench at 8 pages x 4 new tokens: profiles/round1/traffic_pmc.json',
+                         'algorithmic_bytes_per_launch': round(big_by / max(big_n, 1), 1),
                          'launches': int(big_n), 'avg_launch_ms': round(big_ms / max(big_n, 1), 4),
                          'flops_per_launch': round(big_fl / max(big_n, 1), 1),
                          'how': 'HIP events around every launch on the launch stream during the timed steps (cr_profile)'},

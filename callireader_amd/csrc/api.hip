@@ -142,7 +142,7 @@ int cr_profile_read(cr_ctx* c, double* out) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
         double* o = out + (r.big ? 0 : 4);
-        o[0] += 1.0; o[1] += ms; o[2] += r.flops; if (!r.big) o[3] += r.bytes;
+        o[0] += 1.0; o[1] += ms; o[2] += r.flops; o[3] += r.bytes;
         c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
     }
     c->prof_recs.clear();

@@ -126,7 +126,7 @@ int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int6
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* While enabled, every launch of the dense-GEMM kernel made by the stage entry points is bracketed by a pair of
  * HIP events on the launch stream.  cr_profile_read synchronises and returns, for the compute-bound class
- * (M >= 1024 rows) in out[0..3] = {launches, summed kernel ms, summed algorithmic FLOPs (2*M*N*K), 0} and for the
+ * (M >= 1024 rows) in out[0..3] = {launches, summed kernel ms, summed algorithmic FLOPs (2*M*N*K), algorithmic bytes} and for the
  * weight-streaming class (M < 1024) in out[4..7] = {launches, ms, FLOPs, algorithmic bytes (W + A + C)}; then clears. */
 int cr_profile(cr_ctx* ctx, int enable);
 int cr_profile_read(cr_ctx* ctx, double* out8);

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc passes (FETCH_SIZE in one run, WRITE_SIZE in another) of the bench into per-launch
+memory-side traffic of the dominant kernel class, as MI355X_MICROARCH.md "HBM" prescribes:
+  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      (gfx950 reports half the bytes of wide coalesced reads; units KB)
+Note: these counters sit on the L2's fabric side, so Infinity-Cache hits are included.
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+import csv, glob, json, sys
+
+def load(d, counter):
+    f = glob.glob(f'{d}/**/*counter_collection.csv', recursive=True)[0]
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name']
+        fam = 'gemm_tiled_big' if ('gemm256_kernel' in k or 'gemm128_kernel' in k) else ('gemm_skinny' if 'gemm_skinny' in k else None)
+        if fam is None:
+            continue
+        if fam == 'gemm_tiled_big' and 'gemm128' in k and int(r['Grid_Size']) < 8 * 8 * 256:
+            continue            # small 128-tile launches (M < 1024) are not in the roofline class
+        per.setdefault(fam, []).append(float(r['Counter_Value']))
+    return per
+
+fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+out = {}
+for fam in fetch:
+    n = len(fetch[fam])
+    fb, wb = 2 * sum(fetch[fam]) * 1024, sum(write.get(fam, [0])) * 1024
+    out[fam] = {'launches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / max(len(write.get(fam, [1])), 1),
+                'traffic_bytes_per_launch': fb / n + wb / max(len(write.get(fam, [1])), 1)}
+out['_how'] = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) of: python3 bench.py --steps 1 --warmup 0 --pages 8 --new-tokens 4 --no-cpu-baseline --no-vit-extra; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024'
+json.dump(out, open(sys.argv[3], 'w'), indent=1)
+print(json.dumps(out, indent=1))
