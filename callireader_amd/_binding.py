@@ -36,6 +36,7 @@ SIGNATURES = {
     'cr_vit_forward': (i32, [vp, vp, i32, vp, vp]),
     'cr_project': (i32, [vp, vp, i32, vp, vp]),
     'cr_extract_feature': (i32, [vp, vp, i32, vp, vp]),
+    'cr_preprocess': (i32, [vp, vp, i32, i32, vp, i32, vp, vp, i32, vp]),
     'cr_resample': (i32, [vp, vp, i32, vp, vp]),
     'cr_vq': (i32, [vp, vp, i32, vp, vp, vp]),
     'cr_denorm': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
@@ -55,6 +56,10 @@ SIGNATURES = {
     'cr_op_rmsnorm': (i32, [vp, vp, vp, i64, i32, f32, vp]),
     'cr_op_attention': (i32, [vp, vp, vp, vp, C.POINTER(i64), i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]),
 }
+
+
+class PrepJob(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('sx0', 'sy0', 'sw', 'sh', 'ow', 'oh', 'mode', 'tile0', 'cols', 'left', 'top')]
 
 
 class CalliReaderError(RuntimeError):

@@ -110,6 +110,20 @@ class Engine:
         B.check(B.lib.cr_extract_feature(self._h, _p(px), T, _p(out), _stream()), 'cr_extract_feature')
         return out
 
+    # ---- tile preprocessing on the GPU ----
+    def preprocess(self, page_u8, jobs, n_tiles):
+        """page_u8: uint8 (H,W,3) RGB tensor (moved to the device once); jobs: dict rows from preprocess.plan_*."""
+        from .preprocess import norm_lut
+        if getattr(self, '_lut', None) is None:
+            self._lut = norm_lut().to(self.device)
+        page = page_u8.to(self.device).contiguous()
+        assert page.dtype == torch.uint8 and page.dim() == 3 and page.shape[2] == 3
+        arr = (B.PrepJob * len(jobs))(*[B.PrepJob(**j) for j in jobs])
+        out = torch.empty(n_tiles, 3, self.dims.image_size, self.dims.image_size, device=self.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_preprocess(self._h, _p(page), page.shape[0], page.shape[1], arr, len(jobs), _p(self._lut), _p(out),
+                                    n_tiles, _stream()), 'cr_preprocess')
+        return out
+
     # ---- CalliAlign ----
     def resample(self, feats):
         feats = feats.contiguous()

@@ -22,7 +22,7 @@ from PIL import Image
 from .config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, EOS_TOKEN_ID
 from .conversation import get_conv_template
 from .engine import Engine
-from .preprocess import load_image, load_image_2
+from .preprocess import load_image, load_image_2, plan_page, plan_char
 
 
 class InternVLChatModel:
@@ -43,6 +43,7 @@ class InternVLChatModel:
         self.system_message = self.conv_template.system_message            # :194
         self.max_tokens = max_tokens
         self.max_pages = max_pages
+        self.gpu_preprocess = True       # tiles are cut/resized/normalised on the GPU (bit-identical to the PIL path)
         self._kv = None
         self._ready = False
 
@@ -132,11 +133,21 @@ class InternVLChatModel:
                                           'pass boxes=[(x1,y1,x2,y2),...] or a callable detect_model(img)')
             boxes = detect_model(img)
         arr = np.array(img)
-        tiles = []
-        for xyxy in boxes:                                                  # :580-583
-            x1, y1, x2, y2 = int(xyxy[0]), int(xyxy[1]), int(xyxy[2]), int(xyxy[3])
-            tiles.append(load_image_2(Image.fromarray(arr[y1:y2, x1:x2])).to(torch.bfloat16))
-        results = torch.cat(tiles).to(self.device)                          # :585
+        if self.gpu_preprocess:
+            # one page upload, every crop resized/padded/normalised by cr_preprocess (replaces the per-box PIL loop :580-583)
+            h, w = arr.shape[:2]
+            jobs = []
+            for i, xyxy in enumerate(boxes):
+                x1, y1, x2, y2 = [int(v) for v in xyxy[:4]]
+                x1, y1, x2, y2 = max(x1, 0), max(y1, 0), min(x2, w), min(y2, h)        # numpy slicing clips the same way
+                jobs.append(plan_char((x1, y1, x2, y2), i))
+            results = self.engine.preprocess(torch.from_numpy(arr), jobs, len(jobs))
+        else:
+            tiles = []
+            for xyxy in boxes:                                              # :580-583
+                x1, y1, x2, y2 = int(xyxy[0]), int(xyxy[1]), int(xyxy[2]), int(xyxy[3])
+                tiles.append(load_image_2(Image.fromarray(arr[y1:y2, x1:x2])).to(torch.bfloat16))
+            results = torch.cat(tiles).to(self.device)                      # :585
         return self.align_tiles(results, drop_zero, use_hard_vector_quant, verbose)
 
     # ---- generation ----------------------------------------------------------------------------
@@ -251,6 +262,10 @@ class InternVLChatModel:
                     sub_img = Image.fromarray(img[y1:y2, x1:x2])
                     questions = '输出图片中所有文字:'
                     pixel_values = load_image(sub_img).to(torch.bfloat16).to(self.device)
+                elif self.gpu_preprocess:
+                    page = Image.open(img_path).convert('RGB') if isinstance(img_path, str) else img_path.convert('RGB')
+                    jobs, n = plan_page(*page.size)
+                    pixel_values = self.engine.preprocess(torch.from_numpy(np.array(page)), jobs, n)
                 else:
                     pixel_values = load_image(img_path).to(torch.bfloat16).to(self.device)
             except Exception:

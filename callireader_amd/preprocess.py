@@ -105,3 +105,38 @@ def boxes_from_labelme(data):
         x1, y1, x2, y2 = [min(max(0, v), 1) for v in (x1, y1, x2, y2)]
         out.append((int(x1 * w), int(y1 * h), int(x2 * w), int(y2 * h)))
     return out
+
+
+# ---- planning for the GPU path (cr_preprocess): sizes only, no pixel work on the host -----------------------------
+def norm_lut():
+    """bf16 [3][256]: the reference's ToTensor -> Normalize -> .to(bfloat16) applied to every byte value."""
+    p = torch.arange(256, dtype=torch.uint8).float().div(255.0)
+    mean = torch.tensor(IMAGENET_MEAN).view(3, 1)
+    std = torch.tensor(IMAGENET_STD).view(3, 1)
+    return ((p.unsqueeze(0) - mean) / std).to(torch.bfloat16).contiguous()
+
+
+def plan_page(width, height, tile0=0, min_num=1, max_num=12, image_size=448):
+    """Jobs (dict rows) for load_image(page): the tiled resize and, when there is more than one tile, the thumbnail."""
+    cols, rows = tile_grid(width, height, min_num, max_num, image_size)
+    jobs = [dict(sx0=0, sy0=0, sw=width, sh=height, ow=image_size * cols, oh=image_size * rows, mode=1, tile0=tile0, cols=cols, left=0, top=0)]
+    n = cols * rows
+    if n != 1:
+        jobs.append(dict(sx0=0, sy0=0, sw=width, sh=height, ow=image_size, oh=image_size, mode=1, tile0=tile0 + n, cols=1, left=0, top=0))
+        n += 1
+    return jobs, n
+
+
+def plan_char(box, tile, input_size=448):
+    """Job for load_image_2(crop): rescale the longest side into [200,350], centre on a white canvas."""
+    x1, y1, x2, y2 = [int(v) for v in box]
+    width, height = x2 - x1, y2 - y1
+    if max(width, height) <= 200:
+        scale = 200 / max(width, height)
+    elif max(width, height) >= 350:
+        scale = 350 / max(width, height)
+    else:
+        scale = 1.0
+    new_w, new_h = int(width * scale), int(height * scale)
+    return dict(sx0=x1, sy0=y1, sw=width, sh=height, ow=new_w, oh=new_h, mode=0, tile0=tile, cols=1,
+                left=(input_size - new_w) // 2, top=(input_size - new_h) // 2)

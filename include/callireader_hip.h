@@ -73,6 +73,19 @@ int cr_project(cr_ctx* ctx, const void* vit_out, int T, void* out, void* stream)
 /* InternVLChatModel.extract_feature — InternVL/modeling_internvl_chat.py:299-319 (= the two calls above) */
 int cr_extract_feature(cr_ctx* ctx, const void* pixels, int T, void* out, void* stream);
 
+/* ---- tile preprocessing (host side of the reference: utils/utils.py:354-478) ------------------------------- */
+/* One resize job: crop [sx0,sy0,sw,sh] of the page, Pillow Image.resize((ow,oh)) (default BICUBIC, antialiased),
+ * then either mode 0: paste at (left,top) on a white 448x448 canvas = ONE tile `tile0` (load_image_2, :420-452), or
+ * mode 1: cut into 448x448 tiles tile0.. row-major, `cols` per row (dynamic_preprocess, :381-417; cols = ow/448). */
+typedef struct cr_prep_job {
+    int32_t sx0, sy0, sw, sh, ow, oh, mode, tile0, cols, left, top;
+} cr_prep_job;
+/* page_rgb: device uint8 [H][W][3]; jobs: host array; lut: device bf16 [3][256] = bf16((p/255 - mean_c)/std_c) built by
+ * the host with the reference's fp32 expression (build_transform, :354-362); out_tiles: device bf16 [n_tiles,3,448,448].
+ * Bit-identical to the reference's PIL/torch pipeline (tests/test_gpu_prep.py). */
+int cr_preprocess(cr_ctx* ctx, const void* page_rgb, int H, int W, const cr_prep_job* jobs, int n_jobs, const void* lut,
+                  void* out_tiles, int n_tiles, void* stream);
+
 /* ---- CalliAlign ------------------------------------------------------------------------------- */
 /* PerceiverResampler.forward — models/perceiver_resampler.py:81-100:  in [T,256,4096] -> out [T,3,4096] */
 int cr_resample(cr_ctx* ctx, const void* in, int T, void* out, void* stream);

@@ -86,6 +86,11 @@ def test_chat_ocr_matches_oracle_pipeline(setup):
     assert hist == [(ref_q, resp)]
     assert resp == tok.batch_decode(ref_ids)[0].split('<|im_end|>')[0].strip()
     assert gen == dict(num_beams=1, max_new_tokens=6, do_sample=False)       # caller's dict is not mutated
+    # the GPU tile preprocessing (default) and the PIL host path give the same answer
+    m.gpu_preprocess = False
+    resp_pil = m.chat_ocr(tok, None, setup['img'], 'what?', gen, use_p=True, repetition_penalty=1.5, boxes=setup['boxes'])
+    m.gpu_preprocess = True
+    assert resp_pil == resp
     # str return when return_history is False; use_p=False path (no pseudo-tokens)
     ref_ids2, _, _ = oracle_chat_ocr(setup['sd'], setup['dims'], setup['img'], setup['boxes'], tok, 'what?', 4, 1.0, use_p=False)
     r2 = m.chat_ocr(tok, None, setup['img'], 'what?', dict(gen, max_new_tokens=4), use_p=False, repetition_penalty=1.0)
