@@ -29,6 +29,9 @@
 //   * a unit is re-staged one phase (U0) or more after its last ds_read; those reads were retired by the
 //     lgkmcnt(0) ahead of that phase's MFMAs and every wave has passed the closing barrier (WAR).
 //   * the main loop never drains vmcnt to 0; barriers are raw s_barrier (a __syncthreads() would drain the DMA).
+//   * measured nulls (kept out of the code): a second barrier at the start of each phase (-2..3 %), dropping the
+//     closing barriers of phases 2/6 (hazard-free, +-0), compiler-placed fine-grained lgkmcnt waits instead of
+//     lgkmcnt(0) (+-0), write-through (sc1) output stores (-1 %), skipping the epilogue entirely (< 7 %).
 //
 // Persistent: <= 256 workgroups (one per CU) walk the tile list.  The look-ahead of the schedule (1.75 K-tiles)
 // runs straight through a tile boundary: in the last K-tile pair of a tile, phases 2..8 already stage K-tiles 0
@@ -88,7 +91,7 @@ __device__ __forceinline__ void epilogue_rows16(const GemmParams& p, const float
     }
 }
 
-template <int EPI, bool NOBAR26 = false>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -158,8 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #define READ_B(buf, unit, nh)                                                                   \
     _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
         rb[nh][j][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024);
-#define MFMA_Q(mh, nh) MFMA_QB(mh, nh, true)
-#define MFMA_QB(mh, nh, bar)                                                                    \
+#define MFMA_Q(mh, nh)                                                                          \
     WAIT_LGKM0();                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_setprio(1);                                                              \
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                           \
             acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[i][ks], rb[nh][j][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                              \
-    if (bar) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
 
     int t_cur = blockIdx.x;
     if (t_cur >= ntiles) return;
@@ -199,10 +201,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
                 if (has_next) { int nm0, nn0; tile_origin(t_next, nm0, nn0); make_ptrs(nm0, nn0); k2 = 0; }
                 else k2 = nk - 2;                              // nothing follows: re-load dead units with valid addresses
             }
-            // phase 2 (no closing barrier: U1, re-staged in phase 3, was last read in phase 1)
+            // phase 2
             READ_B(0, 2, 1);
             dma(qA[0][0], qA[0][1], k2, 0, 0);
-            MFMA_QB(0, 1, NOBAR26 ? false : true);
+            MFMA_Q(0, 1);
             // phase 3
             READ_A(0, 3);
             dma(qB[0][0], qB[0][1], k2, 0, 1);
@@ -215,10 +217,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             READ_B(1, 1, 0); __builtin_amdgcn_sched_barrier(0); READ_A(1, 0);
             dma(qA[1][0], qA[1][1], k2, 0, 3);
             MFMA_Q(0, 0);
-            // phase 6 (same argument)
+            // phase 6
             READ_B(1, 2, 1);
             dma(qA[0][0], qA[0][1], k2 + 1, 1, 0);
-            MFMA_QB(0, 1, NOBAR26 ? false : true);
+            MFMA_Q(0, 1);
             // phase 7
             READ_A(1, 3);
             dma(qB[0][0], qB[0][1], k2 + 1, 1, 1);
@@ -253,7 +255,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
     static int n_cu = 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess)
             return CR_ERR_HIP;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -261,14 +263,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         attr_set = true;
     }
-    static const int mode = [] { const char* e = getenv("CR_G256_MODE"); return e ? atoi(e) : 0; }();   // tuning aid
-    if (mode == 1 && EPI == EPI_STORE) {
-        static bool a2 = false;
-        if (!a2) { if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI_STORE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return CR_ERR_HIP; a2 = true; }
-        hipLaunchKernelGGL((gemm256_kernel<EPI_STORE, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
-        return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
-    }
-    hipLaunchKernelGGL((gemm256_kernel<EPI, false>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
