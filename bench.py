@@ -227,6 +227,32 @@ def main():
             result['vit_config2'] = {'workload': 'InternViT-300M encoder only, 32 tiles 448x448, bf16', 'tiles_per_s': round(32 / dt, 1),
                                      'ms': round(dt * 1e3, 2), 'tflops': round(32 * 723.6e9 / dt / 1e12, 1),
                                      'mfma_frac': round(32 * 723.6e9 / dt / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if not args.no_vit_extra:
+            # tile preprocessing of one example-shaped page (788x2000, 11 page tiles + 96 character crops)
+            import numpy as np
+            from PIL import Image
+            from callireader_amd import preprocess
+            rng = np.random.default_rng(0)
+            page = rng.integers(0, 256, (2000, 788, 3), dtype=np.uint8)
+            boxes = [(40 + 180 * (i % 4), 30 + 80 * (i // 4), 40 + 180 * (i % 4) + 100 + (i % 5) * 12, 30 + 80 * (i // 4) + 70) for i in range(96)]
+            jobs, n = preprocess.plan_page(788, 2000)
+            jobs += [preprocess.plan_char(b, n + i) for i, b in enumerate(boxes)]
+            page_d = torch.from_numpy(page).to(dev)
+            eng.preprocess(page_d, jobs, n + 96)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                eng.preprocess(page_d, jobs, n + 96)
+            torch.cuda.synchronize()
+            gpu_ms = (time.perf_counter() - t0) / 10 * 1e3
+            t0 = time.perf_counter()
+            pil = Image.fromarray(page)
+            preprocess.load_image(pil)
+            for (x1, y1, x2, y2) in boxes:
+                preprocess.load_image_2(Image.fromarray(page[y1:y2, x1:x2]))
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+            result['preprocess_f1'] = {'workload': '788x2000 page -> 11 page tiles + 96 character tiles (bf16, normalised)', 'gpu_ms_per_page': round(gpu_ms, 3),
+                                       'host_pil_ms_per_page': round(cpu_ms, 1), 'parity': 'bit-exact (tests/test_gpu_prep.py)'}
         if not args.no_cpu_baseline:
             del model
             result['cpu_baseline'] = cpu_baseline()
