@@ -198,7 +198,7 @@ def main():
                                    '(InternViT-300M 24L + mlp1 + PerceiverResampler 4L + 92553-row cosine VQ + InternLM2.5-7B 32L), random-init bf16 weights',
                        'pages_per_gpu': P, 'tiles_per_page': PAGE_TILES + CHAR_TILES, 'prompt_tokens': S_page, 'new_tokens': NEW_TOKENS,
                        'parallelism': f'tile shards + RCCL all-gather of visual embeds, pages round-robin, dp{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm128_kernel (bf16 MFMA GEMM, launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill)',
+            'roofline': {'bound': 'mfma', 'kernel': 'tiled bf16 MFMA GEMM (gemm256_kernel, persistent 256x256 8-phase; gemm128_kernel where it schedules better), launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill',
                          'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': 'bytes per launch on the L2 fabric side (Infinity-Cache hits included), (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this bench at 8 pages x 4 new tokens: profiles/round1/traffic_pmc.json',
@@ -206,7 +206,7 @@ def main():
                          'launches': int(big_n), 'avg_launch_ms': round(big_ms / max(big_n, 1), 4),
                          'flops_per_launch': round(big_fl / max(big_n, 1), 1),
                          'how': 'HIP events around every launch on the launch stream during the timed steps (cr_profile)'},
-            'decode_gemm': {'bound': 'hbm', 'kernel': 'gemm128_kernel launches with M < 1024 (batched decode, resampler rows)',
+            'decode_gemm': {'bound': 'hbm', 'kernel': 'gemm_skinny_kernel (weight streaming, M <= 64: batched decode, LM head) and tiled launches with M < 1024 (resampler rows)',
                             'achieved': round(sm_by / (sm_ms * 1e-3) / 1e9, 1) if sm_ms > 0 else 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                             'frac': round(sm_by / (sm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sm_ms > 0 else 0.0,
                             'launches': int(sm_n), 'kernel_ms_per_step': round(sm_ms / args.steps, 2)},

@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
         const char* kbuf = smem + cur * (2 * TILE);
         const char* vbuf = kbuf + TILE;
-        // decode: a wave whose 32 query rows are all padding only helps staging (wave-uniform branch)
-        if (!SPLIT || wave * 32 < p.Sq) {
+        // a wave whose 32 query rows are all padding (ragged last query block; decode's 4-row blocks) only helps
+        // staging (wave-uniform branch)
+        if (qb * 128 + wave * 32 < p.Sq) {
+        const bool two_blocks = Sk - kt * 64 > 32;       // ragged last key tile: skip its empty 32-key half
 
         // ---- S^T = K . Q^T for two 32-key blocks ----
         f32x16 sacc[2];
@@ -137,10 +139,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) sacc[kb][e] = 0.f;
+            if (kb == 0 || two_blocks) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const bf16x8 kf = *(const bf16x8*)(kbuf + kb * 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 kf = *(const bf16x8*)(kbuf + kb * 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                }
             }
         }
         // ---- scores: reference rounding, masking, online softmax (query = lane) ----
@@ -166,9 +170,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         };
         if (need_mask) score_pass(std::true_type{}); else score_pass(std::false_type{});   // wave-uniform
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
+        // deferred rescale: while no row's maximum grows by more than 8 the reference point m_run stays (P <= e^8 keeps
+        // bf16's relative precision) and the O / l rescale is skipped; the vote is wave-uniform
+        const bool rescale = !__all(mloc - m_run <= 8.0f);
+        const float m_new = rescale ? fmaxf(m_run, mloc) : m_run;
         const float m2 = m_new * LOG2E;                       // exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp_f32
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // raw v_exp_f32: arguments are <= 0
+        const float alpha = rescale ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
@@ -180,14 +187,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
                 psum += pe;
             }
         l_run = l_run * alpha + psum;
+        if (rescale) {
 #pragma unroll
-        for (int db = 0; db < DB; db++)
+            for (int db = 0; db < DB; db++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+                for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++)
+        for (int kb = 0; kb < 2; kb++) {
+            if (kb == 1 && !two_blocks) break;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bf16x8 pf;
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
                 }
             }
+        }
         }
         __syncthreads();
     }

@@ -11,6 +11,13 @@
 #include "norm.hpp"
 
 static constexpr int VIT_CHUNK = 63;   // 63*1025 rows = 253 row-tiles of 256: x4 column tiles = 3.95 rounds of 256 CUs
+// Chunks of 16k-1 tiles (63, 47, 31, 15) put ceil(rows/256) * {4,12,16} GEMM tiles just under a whole number of
+// 256-CU rounds; e.g. 32 tiles are run as 31 + 1 (129 row-tiles -> 125: the 129th held 32 rows and cost a round).
+static int next_chunk(int remaining) {
+    if (remaining >= 63) return 63;
+    for (int c : {47, 31, 15}) if (remaining >= c) return c;
+    return remaining;
+}
 static constexpr int C1 = 1024, C3 = 3072, FF = 4096, TOK = 1025, KPAD = 640;
 
 int vit_finalize(cr_ctx* c, hipStream_t st) {
@@ -119,10 +126,11 @@ int cr_vit_forward(cr_ctx* c, const void* pixels, int T, void* out, void* stream
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_vit_forward: call cr_finalize after loading weights");
     CR_HIP(hipSetDevice(c->device));
     CR_TRY(ws_ensure(c, vit_ws_bytes(T < VIT_CHUNK ? T : VIT_CHUNK)));
-    for (int t0 = 0; t0 < T; t0 += VIT_CHUNK) {
-        const int tc = (T - t0) < VIT_CHUNK ? (T - t0) : VIT_CHUNK;
+    for (int t0 = 0; t0 < T;) {
+        const int tc = next_chunk(T - t0);
         CR_TRY(vit_chunk(c, (const bf16*)pixels + (size_t)t0 * 3 * 448 * 448, tc, (bf16*)out + (size_t)t0 * TOK * C1,
                          (hipStream_t)stream));
+        t0 += tc;
     }
     return CR_OK;
 }
@@ -145,14 +153,15 @@ int cr_extract_feature(cr_ctx* c, const void* pixels, int T, void* out, void* st
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_extract_feature: call cr_finalize after loading weights");
     CR_HIP(hipSetDevice(c->device));
     // ViT output of a chunk sits at the top of the workspace, below it the per-chunk scratch of both stages.
-    for (int t0 = 0; t0 < T; t0 += VIT_CHUNK) {
-        const int tc = (T - t0) < VIT_CHUNK ? (T - t0) : VIT_CHUNK;
+    for (int t0 = 0; t0 < T;) {
+        const int tc = next_chunk(T - t0);
         const size_t inner = vit_ws_bytes(tc) > (size_t)tc * 256 * 4096 * 4 + 4096 ? vit_ws_bytes(tc) : (size_t)tc * 256 * 4096 * 4 + 4096;
         const size_t xbytes = (size_t)tc * TOK * C1 * 2;
         CR_TRY(ws_ensure(c, inner + 256 + xbytes));
         bf16* x = (bf16*)(c->ws + ((inner + 255) & ~(size_t)255));
         CR_TRY(vit_chunk(c, (const bf16*)pixels + (size_t)t0 * 3 * 448 * 448, tc, x, (hipStream_t)stream));
         CR_TRY(project_chunk(c, x, tc, (bf16*)out + (size_t)t0 * 256 * 4096, (hipStream_t)stream));
+        t0 += tc;
     }
     return CR_OK;
 }
