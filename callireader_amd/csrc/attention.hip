@@ -78,14 +78,33 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     const bf16* Kb = p.K + (int64_t)slot * p.k_bs + (int64_t)kvh * p.k_hs;
     const bf16* Vb = p.V + (int64_t)slot * p.v_bs + (int64_t)kvh * p.v_hs;
 
+    // staging addresses: per-lane base pointers of tile 0 are computed once; a full tile adds a wave-uniform offset,
+    // only the ragged last tile re-derives clamped rows (the loop is VALU-bound: no per-tile 64-bit multiplies)
+    const bf16* kbase[IPW];
+    const bf16* vbase[IPW];
+#pragma unroll
+    for (int ii = 0; ii < IPW; ii++) {
+        const int r = (wave * IPW + ii) * RPI + lane / CPR;
+        const int cp = lane % CPR;
+        kbase[ii] = Kb + (int64_t)r * p.k_rs + ((cp ^ kswz<D>(r)) * 8);
+        vbase[ii] = Vb + (int64_t)r * p.v_rs + ((cp ^ vswz<D>(r)) * 8);
+    }
     auto stage = [&](int buf, int kt) {
+        const bool full = kt * 64 + 64 <= Sk;
+        const int64_t koff = (int64_t)kt * 64 * p.k_rs, voff = (int64_t)kt * 64 * p.v_rs;      // scalar
 #pragma unroll
         for (int ii = 0; ii < IPW; ii++) {
-            const int r = (wave * IPW + ii) * RPI + lane / CPR;
-            const int cp = lane % CPR;
-            const int key = min(kt * 64 + r, Sk - 1);
-            const bf16* ks = Kb + (int64_t)key * p.k_rs + ((cp ^ kswz<D>(r)) * 8);
-            const bf16* vs = Vb + (int64_t)key * p.v_rs + ((cp ^ vswz<D>(r)) * 8);
+            const bf16 *ks, *vs;
+            if (full) {
+                ks = kbase[ii] + koff;
+                vs = vbase[ii] + voff;
+            } else {
+                const int r = (wave * IPW + ii) * RPI + lane / CPR;
+                const int cp = lane % CPR;
+                const int key = min(kt * 64 + r, Sk - 1);
+                ks = Kb + (int64_t)key * p.k_rs + ((cp ^ kswz<D>(r)) * 8);
+                vs = Vb + (int64_t)key * p.v_rs + ((cp ^ vswz<D>(r)) * 8);
+            }
             char* dst = smem + buf * (2 * TILE) + (wave * IPW + ii) * 1024;
             __builtin_amdgcn_global_load_lds(CR_GLB(ks), CR_LDS(dst), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(CR_GLB(vs), CR_LDS(dst + TILE), 16, 0, 0);
