@@ -10,13 +10,15 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_row8(const GemmParams& p, int gm, int gn, const float* v) {
     // v[0..7]: fp32 accumulators of row gm, columns gn..gn+7 (gn % 8 == 0, gn + 8 <= N)
     float x[8];
+    // EPI_STORE / EPI_PATCH-free paths whose only rounding is the final cast skip the explicit round-trip
+    constexpr bool ROUND_NOW = (EPI != EPI_STORE);
     if (p.bias) {
         bf16x8 b = *(const bf16x8*)(p.bias + gn);
 #pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = rbf(v[e] + bf2f(b[e]));
+        for (int e = 0; e < 8; e++) x[e] = ROUND_NOW ? rbf(v[e] + bf2f(b[e])) : v[e] + bf2f(b[e]);
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; e++) x[e] = rbf(v[e]);
+        for (int e = 0; e < 8; e++) x[e] = ROUND_NOW ? rbf(v[e]) : v[e];
     }
     if (EPI == EPI_F32) {
         float* c = (float*)p.C + (int64_t)gm * p.ldc + gn;
