@@ -2,7 +2,8 @@
 
 Differences that the scope forces: character boxes come from a labelme-style JSON next to the image
 (`<image>.json`, the format of examples/0.json) or from --boxes, because the YOLO/OrderFormer front end is out of
-scope; the tokenizer is loaded with transformers' AutoTokenizer from --model (the reference's own tokenizer files).
+scope; the tokenizer is the engine's own reader of the reference's tokenizer files under --model
+(callireader_amd/tokenization_internlm2.py, pinned against the sentencepiece library in tests/test_tokenizer.py).
 """
 import argparse
 import json
@@ -67,9 +68,11 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if not isinstance(args.tgt, str):
         raise ValueError(f'The target should a string, not a instance of {type(args.tgt)}!')
-    from transformers import AutoTokenizer
+    from .tokenization_internlm2 import InternLM2Tokenizer
     model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16).eval().cuda()
-    tokenizer = AutoTokenizer.from_pretrained(args.model, trust_remote_code=True)
+    # the engine's own reader of tokenizer.model (+ tokenizer_config.json / added_tokens.json): the reference's
+    # AutoTokenizer path needs sentencepiece==0.2.0; any HF-style tokenizer object works with chat_ocr as well
+    tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
     generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
     if is_image(args.tgt):
         print('Single image recognition mode.')
