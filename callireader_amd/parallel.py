@@ -2,11 +2,12 @@
 'gloo' in CPU tests).
 
 The reference has no inference parallelism; this is the new exchange step north_star asks for:
-tiles of a batch of pages are independent through ViT -> projector -> resampler -> VQ -> de-norm, so the flat tile
-list is split contiguously and evenly over ranks (reading order preserved), each rank runs the visual stage on its
-shard, and ONE all-gather per tensor kind hands every rank the embeddings of all tiles.  Pages are then owned
-round-robin (page p -> rank p % world) for the LLM, so pages of different length balance.  Only rows travel:
-24 576 B per character tile (3 pseudo-tokens) and 2.1 MB per page tile (256 visual tokens).
+tiles of a batch of pages are independent through ViT -> projector -> resampler -> VQ -> de-norm.  The character
+tiles (90 % of the visual work, and what varies most from page to page) form one flat list that is split contiguously
+and evenly over ranks (reading order preserved); each rank runs the visual stage on its shard and ONE all-gather hands
+every rank all pseudo-token embeddings (24 576 B per tile).  Pages are owned round-robin (page p -> rank p % world)
+for the LLM; a page's own tiles (2.1 MB of embeddings each, needed by nobody else) are encoded by its owner.
+`all_gather_rows` is generic: it also carries the 2.1 MB page-tile rows when a caller shards those too.
 """
 import torch
 import torch.distributed as dist

@@ -37,6 +37,7 @@ def run(pages, vit_all, pseudo_all):
     return m.generate_pages(embeds, max_new_tokens=NEW, eos_token_id=None)
 
 
+# (a) generic path: page tiles sharded contiguously too, both kinds gathered
 lo, hi = shard_range(n_pages * PT, world, rank)
 clo, chi = shard_range(n_pages * CT, world, rank)
 vit_all = all_gather_rows(m.extract_feature(page_px[lo:hi].cuda()), n_pages * PT)
@@ -44,6 +45,14 @@ pseudo, _ = m.align_tiles(char_px[clo:chi].cuda())
 pseudo_all = all_gather_rows(pseudo.reshape(-1, 3, dims.llm_hidden), n_pages * CT)
 mine = owned_pages(n_pages, world, rank)
 outs = dict(zip(mine, run(mine, vit_all, pseudo_all)))
+# (b) bench.py's flow: page tiles encoded by the page owner, only pseudo-tokens travel
+own_px = torch.cat([page_px[p * PT:(p + 1) * PT] for p in mine])
+vit_own = m.extract_feature(own_px.cuda())
+vit_scatter = torch.zeros_like(vit_all)
+for j, p in enumerate(mine):
+    vit_scatter[p * PT:(p + 1) * PT] = vit_own[j * PT:(j + 1) * PT]
+outs_b = dict(zip(mine, run(mine, vit_scatter, pseudo_all)))
+assert outs_b == outs, (outs_b, outs)
 gathered = [None] * world
 dist.all_gather_object(gathered, outs)
 if rank == 0:
