@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- FIRST: PyTorch-ROCm bundles its own libamdhip64; loading ours before it would start a
 #                              second HIP runtime in the process ("no ROCm-capable device is detected")
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcallireader_hip.so')
+_LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcallireader_hip.so')   # CR_HIP_LIB: A/B a second build (development aid)
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3

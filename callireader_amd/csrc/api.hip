@@ -157,6 +157,9 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)Wt; p.ldw = ldw; p.C = C; p.ldc = ldc;
     p.bias = (const bf16*)bias; p.scale = (const bf16*)scale; p.res = (const bf16*)res; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K; p.group = group;
+    const int kern = (epi >> 8) & 0xff;           // tests pin a kernel: 1 = 128x128, 2 = 256x256, 3 = skinny
+    p.kernel = kern == 1 ? 128 : kern == 2 ? 256 : kern == 3 ? 1 : 0;
+    epi &= 0xff;
     int r = launch_gemm(epi, p, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_gemm(epi=%d, M=%d, N=%d, K=%d) rejected or failed to launch", epi, M, N, K);
     return CR_OK;

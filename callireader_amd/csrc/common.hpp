@@ -63,6 +63,7 @@ struct GemmParams {
     const bf16* res; int64_t ldr;   // residual rows (EPI_LS_RES / EPI_RES) or pos-emb (EPI_PATCH)
     int M, N, K;
     int group;                 // EPI_PATCH: patches per tile (1024)
+    int kernel;                // 0 = dispatcher's choice; 128 | 256 | 1 (skinny) pin one (cr_op_gemm's tests only)
 };
 
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream);

@@ -146,9 +146,14 @@ int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return CR_ERR_ARG;
     if ((p.lda & 7) || (p.ldw & 7)) return CR_ERR_ARG;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.C & 15)) return CR_ERR_ARG;
-    static const int force = [] { const char* e = getenv("CR_GEMM_FORCE"); return e ? atoi(e) : 0; }();   // tuning aid: 128 | 256
-    if (force != 128 && force != 256 && gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
-    if (force != 128 && (force == 256 ? (p.K % 128) == 0 : gemm256_supported(epi, p))) return launch_gemm256(epi, p, stream);   // large M: 256x256 8-phase kernel
+    static const int env_force = [] { const char* e = getenv("CR_GEMM_FORCE"); return e ? atoi(e) : 0; }();   // tuning aid: 128 | 256
+    const int force = p.kernel ? p.kernel : env_force;
+    if (force == 1) return gemm_skinny_supported(epi, p) ? launch_gemm_skinny(epi, p, stream) : CR_ERR_ARG;
+    if (force == 256) return (p.K % 128) == 0 ? launch_gemm256(epi, p, stream) : CR_ERR_ARG;
+    if (force != 128) {
+        if (gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
+        if (gemm256_supported(epi, p)) return launch_gemm256(epi, p, stream);           // large M: 256x256 8-phase kernel
+    }
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE>(p, stream);
         case EPI_GELU: return launch_t<EPI_GELU>(p, stream);

@@ -52,8 +52,9 @@ constexpr int LDS_MAIN2 = 2 * KBUF;               // 131072
 constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per wave = 163840 (all of the CU's LDS)
 
 #define WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)   /* lgkmcnt(0); the builtin (unlike inline asm) is seen by the compiler's own wait insertion */
 
 // rows [row0, row0+16) x cols [col0, col0+64) from the wave-private slice st[16][64]
 template <int EPI>
@@ -120,29 +121,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // DMA sources: this wave fills sub-tiles s = 2*wave + e (e = 0,1) of every unit
     //   A units: s -> (wave row s>>3, fragment (s>>1)&3, ksub s&1);  B units: s -> (wave col s>>2, fragment (s>>1)&1, ksub s&1)
     //   lane -> row lane>>2 of the sub-tile, 16-B chunk (lane&3) ^ 2*(row>>3)
+    // kept as 32-bit byte offsets from the (uniform) operand base: operands are < 4 GiB, and the fragment double
+    // buffer below needs the registers
     const int srow = lane >> 2;
     const int schunk = (lane & 3) ^ ((srow >> 3) << 1);
-    const bf16* qA[2][2];     // [mh][e]   pointer set used by phases 2..8 (may already be the NEXT tile's)
-    const bf16* qB[2][2];     // [nh][e]
-    const bf16* p1A[2];       // U3 (A mh=1) of the tile being computed, for phase 1
+    uint32_t qA[2];           // [mh]   offsets used by phases 2..8 (may already be the NEXT tile's); piece e = 1 is 64 B on
+    uint32_t qB[2];           // [nh]
+    uint32_t p1A;             // U3 (A mh=1) of the tile being computed, for phase 1
     auto make_ptrs = [&](int m0, int n0) {
+        // sub-tiles 2*wave and 2*wave + 1 are the two k-halves (ksub 0 / 1) of the same 16 rows
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int s = 2 * wave + e;
-            const int ksub = s & 1;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int arow = m0 + (s >> 3) * 128 + h * 64 + ((s >> 1) & 3) * 16 + srow;
-                const int brow = n0 + (s >> 2) * 64 + h * 32 + ((s >> 1) & 1) * 16 + srow;
-                qA[h][e] = p.A + (int64_t)min(arow, p.M - 1) * p.lda + ksub * 32 + schunk * 8;
-                qB[h][e] = p.W + (int64_t)min(brow, p.N - 1) * p.ldw + ksub * 32 + schunk * 8;
-            }
+        for (int h = 0; h < 2; h++) {
+            const int arow = m0 + (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + srow;
+            const int brow = n0 + (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + srow;
+            qA[h] = (uint32_t)(((int64_t)min(arow, p.M - 1) * p.lda + schunk * 8) * 2);
+            qB[h] = (uint32_t)(((int64_t)min(brow, p.N - 1) * p.ldw + schunk * 8) * 2);
         }
     };
-    auto dma = [&](const bf16* s0, const bf16* s1, int kt, int buf, int u) {
+    auto dma = [&](const bf16* base, uint32_t o, int kt, int buf, int u) {
         char* dst = smem + buf * KBUF + u * UNIT + (2 * wave) * 1024;
-        __builtin_amdgcn_global_load_lds(CR_GLB(s0 + (int64_t)kt * BK2), CR_LDS(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(CR_GLB(s1 + (int64_t)kt * BK2), CR_LDS(dst + 1024), 16, 0, 0);
+        const char* src = (const char*)base + (int64_t)kt * (BK2 * 2);
+        __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst), 16, 0, 0);
+        // the instruction's immediate offset is added to the global AND to the LDS address: M0 is set 64 short
+        __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst + 1024 - 64), 16, 64, 0);
     };
 
     const int lrow = lane & 15;
@@ -152,23 +153,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     float* st = (float*)(smem + LDS_MAIN2) + wave * 1024;
 
     f32x4 acc[8][4];
-    bf16x8 ra[4][2];          // A fragments of the current quadrant row: [i][ksub]
-    bf16x8 rb[2][2][2];       // B fragments: [nh][j][ksub]
+    bf16x8 ra0[4][2], ra1[4][2];      // A fragments [i][ksub]: mh = 0 lives in ra0, mh = 1 in ra1
+    bf16x8 rbx[2][2], rby[2][2];      // B fragments [j][ksub]: the two halves swap registers every K-tile
 
-#define READ_A(buf, unit)                                                                       \
+#define READ_A(dst, buf, unit)                                                                  \
     _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
-        ra[i][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + a_sub + (i * 2 + ks) * 1024);
-#define READ_B(buf, unit, nh)                                                                   \
+        dst[i][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + a_sub + (i * 2 + ks) * 1024);
+#define READ_B(dst, buf, unit)                                                                  \
     _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
-        rb[nh][j][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024);
-#define MFMA_Q(mh, nh)                                                                          \
+        dst[j][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024);
+    // one phase: operands of THIS phase were read a phase ago (retired by the lgkmcnt(0)); the reads for the NEXT
+    // phase and this phase's two DMA pieces are issued ahead of the 16 MFMAs and complete underneath them
+#define PHASE(mh, nh, RA, RB, PREFETCH, DMA)                                                    \
     WAIT_LGKM0();                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    PREFETCH;                                                                                   \
+    DMA;                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_setprio(1);                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int i = 0; i < 4; i++) \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                           \
-            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[i][ks], rb[nh][j][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
+            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RA[i][ks], RB[j][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    WAIT_VM8();                                                                                 \
     __builtin_amdgcn_s_barrier();
 
     int t_cur = blockIdx.x;
@@ -177,10 +185,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     tile_origin(t_cur, m0, n0);
     make_ptrs(m0, n0);
     // ---- cold start (first tile of this workgroup only): K-tile 0 complete, U0..U2 of K-tile 1 in flight ----
-    dma(qA[0][0], qA[0][1], 0, 0, 0); dma(qB[0][0], qB[0][1], 0, 0, 1); dma(qB[1][0], qB[1][1], 0, 0, 2); dma(qA[1][0], qA[1][1], 0, 0, 3);
-    dma(qA[0][0], qA[0][1], 1, 1, 0); dma(qB[0][0], qB[0][1], 1, 1, 1); dma(qB[1][0], qB[1][1], 1, 1, 2);
+    dma(p.A, qA[0], 0, 0, 0); dma(p.W, qB[0], 0, 0, 1); dma(p.W, qB[1], 0, 0, 2); dma(p.A, qA[1], 0, 0, 3);
+    dma(p.A, qA[0], 1, 1, 0); dma(p.W, qB[0], 1, 1, 1); dma(p.W, qB[1], 1, 1, 2);
     WAIT_VM6();
     __builtin_amdgcn_s_barrier();
+    READ_A(ra0, 0, 0); READ_B(rbx, 0, 1);
 
     while (true) {
 #pragma unroll
@@ -191,44 +200,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const bool has_next = t_next < ntiles;
 
         for (int kt = 0; kt < nk; kt += 2) {
-            p1A[0] = qA[1][0]; p1A[1] = qA[1][1];
+            p1A = qA[1];
             int k2 = kt + 2;                                   // K-tile staged by phases 2..5 (and k2 + 1 by 6..8)
-            // phase 1
-            READ_B(0, 1, 0); __builtin_amdgcn_sched_barrier(0); READ_A(0, 0);
-            dma(p1A[0], p1A[1], kt + 1, 1, 3);
-            MFMA_Q(0, 0);
+            PHASE(0, 0, ra0, rbx, READ_B(rby, 0, 2), dma(p.A, p1A, kt + 1, 1, 3));
             if (k2 >= nk) {                                    // last pair: the look-ahead belongs to the next tile
                 if (has_next) { int nm0, nn0; tile_origin(t_next, nm0, nn0); make_ptrs(nm0, nn0); k2 = 0; }
                 else k2 = nk - 2;                              // nothing follows: re-load dead units with valid addresses
             }
-            // phase 2
-            READ_B(0, 2, 1);
-            dma(qA[0][0], qA[0][1], k2, 0, 0);
-            MFMA_Q(0, 1);
-            // phase 3
-            READ_A(0, 3);
-            dma(qB[0][0], qB[0][1], k2, 0, 1);
-            MFMA_Q(1, 1);
-            // phase 4
-            dma(qB[1][0], qB[1][1], k2, 0, 2);
-            WAIT_VM6();
-            MFMA_Q(1, 0);
-            // phase 5
-            READ_B(1, 1, 0); __builtin_amdgcn_sched_barrier(0); READ_A(1, 0);
-            dma(qA[1][0], qA[1][1], k2, 0, 3);
-            MFMA_Q(0, 0);
-            // phase 6
-            READ_B(1, 2, 1);
-            dma(qA[0][0], qA[0][1], k2 + 1, 1, 0);
-            MFMA_Q(0, 1);
-            // phase 7
-            READ_A(1, 3);
-            dma(qB[0][0], qB[0][1], k2 + 1, 1, 1);
-            MFMA_Q(1, 1);
-            // phase 8
-            dma(qB[1][0], qB[1][1], k2 + 1, 1, 2);
-            WAIT_VM6();
-            MFMA_Q(1, 0);
+            PHASE(0, 1, ra0, rby, READ_A(ra1, 0, 3), dma(p.A, qA[0], k2, 0, 0));
+            PHASE(1, 1, ra1, rby, READ_A(ra0, 1, 0), dma(p.W, qB[0], k2, 0, 1));
+            PHASE(1, 0, ra1, rbx, READ_B(rby, 1, 1), dma(p.W, qB[1], k2, 0, 2));
+            PHASE(0, 0, ra0, rby, READ_B(rbx, 1, 2), dma(p.A, qA[1], k2, 0, 3));
+            PHASE(0, 1, ra0, rbx, READ_A(ra1, 1, 3), dma(p.A, qA[0], k2 + 1, 1, 0));
+            PHASE(1, 1, ra1, rbx, READ_A(ra0, 0, 0), dma(p.W, qB[0], k2 + 1, 1, 1));
+            PHASE(1, 0, ra1, rby, READ_B(rbx, 0, 1), dma(p.W, qB[1], k2 + 1, 1, 2));
         }
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----

@@ -227,13 +227,14 @@ class KVCache:
 
 
 # ---- single operators (tests / profiling) ----
-def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None):
+def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None, kernel=0):
+    """kernel: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent, 3 weight-streaming (tests pin one)."""
     M, K = A.shape
     N = Wt.shape[0]
     ncols = n_out if n_out is not None else (N // 2 if epi == 4 else N)
     mrows = M if epi != 5 else (M // group) * (group + 1)
     Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
-    B.check(B.lib.cr_op_gemm(epi, _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
+    B.check(B.lib.cr_op_gemm(epi | (kernel << 8), _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')
     return Cc
 

@@ -145,7 +145,9 @@ int cr_profile(cr_ctx* ctx, int enable);
 int cr_profile_read(cr_ctx* ctx, double* out8);
 
 /* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
-/* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32 */
+/* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32.
+ * Bits 8..15 of epi pin a kernel for the unit tests: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent,
+ * 3 weight-streaming (M <= 64); a pinned kernel that cannot take the shape returns CR_ERR_ARG. */
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
                void* stream);
