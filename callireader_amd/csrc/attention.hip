@@ -25,16 +25,6 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-// (a, b) -> bf16-rounded (RNE) values as floats: the cast of the pair compiles to one v_cvt_pk_bf16_f32; unpacking
-// through integer ops keeps LLVM from folding the rounding away.  Deliberately NOT inline asm: as the first reader
-// of MFMA results an asm statement gets no MFMA->VALU wait states from hipcc (NaNs observed).
-__device__ __forceinline__ void round_pair_bf16(float a, float b, float& ra, float& rb2) {
-    const bf16x2 v = {(bf16)a, (bf16)b};
-    const unsigned pk = __builtin_bit_cast(unsigned, v);
-    ra = __uint_as_float(pk << 16);
-    rb2 = __uint_as_float(pk & 0xffff0000u);
-}
-
 template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
 template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
 

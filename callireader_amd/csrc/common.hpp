@@ -27,6 +27,16 @@ __device__ __forceinline__ float rbf(float x) {
     return __uint_as_float(u);
 }
 
+// (a, b) -> bf16-rounded (RNE) values as floats: the cast of the pair compiles to one v_cvt_pk_bf16_f32; unpacking
+// through integer ops keeps LLVM from folding the rounding away.  Deliberately NOT inline asm: as the first reader
+// of MFMA results an asm statement gets no MFMA->VALU wait states from hipcc (NaNs observed).
+__device__ __forceinline__ void round_pair_bf16(float a, float b, float& ra, float& rb2) {
+    const bf16x2 v = {(bf16)a, (bf16)b};
+    const unsigned pk = __builtin_bit_cast(unsigned, v);
+    ra = __uint_as_float(pk << 16);
+    rb2 = __uint_as_float(pk & 0xffff0000u);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

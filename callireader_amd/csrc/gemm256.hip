@@ -4,7 +4,8 @@
 // Geometry: 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile = 8 x 4 accumulators of
 // v_mfma_f32_16x16x32_bf16 (128 VGPRs).  Per K-tile (64 deep) a wave runs 4 phases of 16 MFMAs, one
 // 64 x 32 quadrant (mh, nh) of its sub-tile each: (0,0) (0,1) (1,1) (1,0), so consecutive phases reuse
-// either the A or the B fragments already in registers.
+// either the A or the B fragments already in registers.  The weight fragment is the MFMA's A operand, so a lane's
+// accumulator holds four consecutive output COLUMNS of one row (what the epilogue wants).
 //
 // LDS: 2 K-tile buffers x 4 units x 16 KiB = 128 KiB.  A unit holds what ONE phase's ds_reads consume for ALL
 // waves: U0 = A rows of quadrant-row mh=0 (of both wave rows), U1 = B cols of nh=0 (of all four wave columns),
@@ -13,32 +14,47 @@
 // a unit.  Inside a sub-tile the 16-B chunk of rows 8..15 is XORed with 2 (on the DMA source address and on
 // the ds_read_b128 address), which makes the fragment read bank-conflict free.
 //
-// Schedule (one iteration = K-tiles 2i [even buffer] and 2i+1 [odd buffer], 8 phases):
+// Schedule.  A phase is two slots, each closed by s_barrier:
+//   memory slot: this phase's ds_read_b128s, the two DMA pieces of one unit, s_waitcnt vmcnt(8)
+//   matrix slot: s_waitcnt lgkmcnt(0), 16 MFMAs at s_setprio 1
+// and waves 4..7 run ONE SLOT BEHIND waves 0..3 (they take an extra barrier at the top of each tile, waves 0..3 one
+// at its end).  The two waves that share a SIMD are w and w + 4, so each SIMD always has one wave issuing MFMAs
+// while its partner issues LDS reads and DMA: lock-stepped partners left the matrix pipe idle through every
+// issue burst (measured on 8192^3 and the prefill shapes: 8-phase lock-step 1.36-1.38 PFLOP/s, + fragments
+// prefetched one phase ahead 1.41-1.42, this slot stagger 1.49-1.51; in-kernel stamps: 594-623 clocks per phase
+// against 512 of pure MFMA issue).
+//   one iteration = K-tiles 2i [even buffer] and 2i+1 [odd buffer], 8 phases:
 //   phase   reads (ds_read_b128 -> regs)        MFMA quadrant     DMA issued (2 per wave)
-//     1     even U0 (8) + U1 (4)                 (0,0)             odd  U3  of K-tile 2i+1
-//     2     even U2 (4)                          (0,1)             even U0  of K-tile 2i+2
-//     3     even U3 (8)                          (1,1)             even U1
-//     4     -                                    (1,0)             even U2      then s_waitcnt vmcnt(6)
-//     5     odd  U0 + U1                         (0,0)             even U3  of K-tile 2i+2
-//     6     odd  U2                              (0,1)             odd  U0  of K-tile 2i+3
-//     7     odd  U3                              (1,1)             odd  U1
-//     8     -                                    (1,0)             odd  U2      then s_waitcnt vmcnt(6)
-//   * vmcnt(6) leaves the three most recent units in flight: at phase 4 everything issued up to phase 1 has
-//     landed = the whole odd K-tile, read from phase 5 on; at phase 8 the whole even K-tile of the next iteration.
-//     The wait sits before the phase's closing barrier, the first read one phase later (RAW via wait + barrier).
-//   * a unit is re-staged one phase (U0) or more after its last ds_read; those reads were retired by the
-//     lgkmcnt(0) ahead of that phase's MFMAs and every wave has passed the closing barrier (WAR).
+//     1     even U0 (8) + U1 (4)                 (0,0)             odd  U2  of K-tile 2i+1
+//     2     even U2 (4)                          (0,1)             odd  U3
+//     3     even U3 (8)                          (1,1)             even U0  of K-tile 2i+2
+//     4     -                                    (1,0)             even U1
+//     5     odd  U0 + U1                         (0,0)             even U2
+//     6     odd  U2                              (0,1)             even U3
+//     7     odd  U3                              (1,1)             odd  U0  of K-tile 2i+3
+//     8     -                                    (1,0)             odd  U1
+//   * RAW: a unit is staged 5 or 6 phases before the phase that reads it; vmcnt(8) at the end of every memory slot
+//     leaves the four most recent units in flight, so what the NEXT phase reads has landed in every wave before the
+//     barrier that precedes those reads (both wave groups: the late group waits one slot later, the early group
+//     reads one slot after that).
+//   * WAR: a unit is re-staged two phases (or more) after the phase that read it: the reads of both groups were
+//     retired by the lgkmcnt(0) of their matrix slots, the later of which ends one full slot before the early
+//     group's DMA into the unit.
 //   * the main loop never drains vmcnt to 0; barriers are raw s_barrier (a __syncthreads() would drain the DMA).
-//   * measured nulls (kept out of the code): a second barrier at the start of each phase (-2..3 %), dropping the
-//     closing barriers of phases 2/6 (hazard-free, +-0), compiler-placed fine-grained lgkmcnt waits instead of
-//     lgkmcnt(0) (+-0), write-through (sc1) output stores (-1 %), skipping the epilogue entirely (< 7 %).
+//   * measured nulls (kept out of the code): a second barrier at the start of each lock-stepped phase (-2..3 %),
+//     write-through (sc1) output stores (-1 %), spreading the workgroups' start times over 8-32 us (+-0: the
+//     epilogue's stores are bound per CU, not by the chip), skipping the output stores entirely (10 % at K = 1024).
 //
-// Persistent: <= 256 workgroups (one per CU) walk the tile list.  The look-ahead of the schedule (1.75 K-tiles)
-// runs straight through a tile boundary: in the last K-tile pair of a tile, phases 2..8 already stage K-tiles 0
-// and 1 of the workgroup's NEXT tile, so the next tile starts in exactly the prologue state and no CU ever sits
-// in a cold-start load burst (measured: with every CU starting a tile at once, the 112 KB/CU prologue costs ~5 us
-// per tile at ~11 B/clk/CU; PMC: MFMA-busy 46 % at K = 1024 vs 61 % at K = 8192 before this change).
-// The epilogue therefore may not touch the K buffers: it stages 16-row slices through a separate 4 KiB per wave.
+// Persistent: <= 256 workgroups (one per CU) walk the tile list.  The look-ahead of the schedule runs straight
+// through a tile boundary: in the last K-tile pair of a tile, phases 3..8 already stage K-tile 0 and U0/U1 of
+// K-tile 1 of the workgroup's NEXT tile, so no CU ever sits in a cold-start load burst (measured: with every CU
+// starting a tile at once the prologue costs ~5 us per tile at ~11 B/clk/CU).  The epilogue therefore may not touch
+// the K buffers: it stages 16-row bf16 slices through a separate 4 KiB per wave.  The look-ahead is drained
+// (vmcnt(0)) before the epilogue, which lets slots 1..4 of the next tile skip their counted wait: on the in-order
+// counter that wait would otherwise sit behind the tile's output stores.
+// In-kernel stamps (-DCR_DIAG_STAMPS, s_memtime into the buffer passed as `scale`): K = 1024 tiles spend 39.1 k
+// clocks in the main loop, 0.4 k draining the look-ahead and 6.0 k in the epilogue; the sustained clock under this
+// load is ~1.3 GHz, which is what keeps the absolute rate under half the 2.4 GHz peak.
 #include <stdlib.h>
 
 #include "gemm_epilogue.hpp"
@@ -56,39 +72,158 @@ constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per 
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)   /* lgkmcnt(0); the builtin (unlike inline asm) is seen by the compiler's own wait insertion */
 
-// rows [row0, row0+16) x cols [col0, col0+64) from the wave-private slice st[16][64]
+// ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------------------------
+// The MFMAs run with the operands swapped (weights as the A operand), so a lane's accumulator acc[mf][j][0..3] is
+// row m = mf*16 + (lane & 15), columns n = j*16 + (lane >> 4)*4 + 0..3: four CONSECUTIVE columns.  Everything that is
+// per element and per column is applied right there (bias, the bf16 rounding of the linear output, GELU, LayerScale),
+// the four values are packed to bf16 and leave as ONE 8-byte ds_write into a 16 x 64 bf16 slice (2 KiB, two slices
+// per wave so that staging slice mf + 1 does not wait for slice mf's read-back).  The read-back hands every lane 8
+// consecutive columns of a row (16 B): residual / position rows are added there and the result goes out as 16-byte
+// stores.  fp32 staging through ds_write_b32 (64 B/clk/CU for all 8 waves) used to bound the epilogue at ~4 k cycles.
+//   slice image: row r at r*128 B; the 8-byte slot s of a row sits at (s ^ r): the 16 lanes of a ds_write_b64 group
+//   (rows 0..15, same s) hit 16 different bank pairs, and the 16-byte read-back chunk c = (slot pair) is found at
+//   c ^ (r >> 1) with its halves exchanged when r is odd.
 template <int EPI>
-__device__ __forceinline__ void epilogue_rows16(const GemmParams& p, const float* st, int row0, int col0, int lane) {
+__device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&bias_f)[4][4], const float (&scale_f)[4][4],
+                                            bool has_bias, char* buf, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float x[4] = {a[j][0], a[j][1], a[j][2], a[j][3]};
+        if (has_bias) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] += bias_f[j][e];
+        }
+        if (EPI == EPI_GELU || EPI == EPI_LS_RES) {          // bf16(acc + bias) is a value of its own before the next op
+            round_pair_bf16(x[0], x[1], x[0], x[1]);
+            round_pair_bf16(x[2], x[3], x[2], x[3]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] = EPI == EPI_GELU ? gelu_erf(x[e]) : x[e] * scale_f[j][e];
+        }
+        const bf16x4 o = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+        *(bf16x4*)(buf + r * 128 + (((j * 4 + g) ^ r) << 3)) = o;
+    }
+}
+
+// 16-byte chunk c (columns 8c .. 8c+7) of staged row r
+__device__ __forceinline__ bf16x8 read_chunk(const char* buf, int r, int c) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const u32x4 v = *(const u32x4*)(buf + r * 128 + ((c ^ (r >> 1)) << 4));
+    const bool odd = r & 1;
+    const u32x4 w = {odd ? v[2] : v[0], odd ? v[3] : v[1], odd ? v[0] : v[2], odd ? v[1] : v[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[8][4], char* stg, int row_base, int col0,
+                                              int lane) {
+    constexpr bool ADD_ROWS = (EPI == EPI_LS_RES || EPI == EPI_RES);
+    const bool has_bias = p.bias != nullptr;
+    const bool full_n = col0 + 64 <= p.N;
+    // ---- per-column operands in the accumulator layout
+    float bias_f[4][4], scale_f[4][4];
+    {
+        const bool vec = full_n && ((((uintptr_t)p.bias) | ((uintptr_t)p.scale)) & 7) == 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = col0 + j * 16 + (lane >> 4) * 4;
+            if (has_bias) {
+                if (vec) {
+                    const bf16x4 b = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) bias_f[j][e] = bf2f(b[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) bias_f[j][e] = n + e < p.N ? bf2f(p.bias[n + e]) : 0.f;
+                }
+            }
+            if (EPI == EPI_LS_RES) {
+                if (vec) {
+                    const bf16x4 b = *(const bf16x4*)(p.scale + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) scale_f[j][e] = bf2f(b[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) scale_f[j][e] = n + e < p.N ? bf2f(p.scale[n + e]) : 0.f;
+                }
+            }
+        }
+    }
+
     if (EPI == EPI_SWIGLU) {
-        const int row = lane >> 2, oc = lane & 3;
-        const int gm = row0 + row, gno = col0 / 2 + oc * 8;
-        if (gm < p.M && gno + 8 <= p.N / 2) {
-            const float* sp = st + row * 64 + oc * 16;
+        // staged columns are [8 gate | 8 up] per 16: a lane takes one such pair -> 8 outputs
+        const int r = lane >> 2, oc = lane & 3;
+        const int gno = col0 / 2 + oc * 8;
+#pragma unroll
+        for (int mf = 0; mf < 8; mf++) {
+            char* buf = stg + (mf & 1) * 2048;
+            stage_slice<EPI>(acc[mf], bias_f, scale_f, has_bias, buf, lane);
+            __builtin_amdgcn_wave_barrier();
+            const int gm = row_base + mf * 16 + r;
+            const bf16x8 gt = read_chunk(buf, r, 2 * oc), up = read_chunk(buf, r, 2 * oc + 1);
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float g = rbf(sp[e]), u = rbf(sp[8 + e]);
-                o[e] = f2bf(rbf(silu(g)) * u);
-            }
-            *(bf16x8*)((bf16*)p.C + (int64_t)gm * p.ldc + gno) = o;
+            for (int e = 0; e < 8; e++) o[e] = f2bf(rbf(silu(bf2f(gt[e]))) * bf2f(up[e]));
+            if (gm < p.M && gno + 8 <= p.N / 2) *(bf16x8*)((bf16*)p.C + (int64_t)gm * p.ldc + gno) = o;
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
-    const bool vec_ok = ((p.ldc & 7) == 0) || (EPI == EPI_F32);
+
+    const int rin = lane >> 3, c = lane & 7, gn = col0 + c * 8;
+    const bool vec_ok = gn + 8 <= p.N && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (p.ldr & 7) == 0;
+    // rows to add after the read-back (residual stream / position embedding), requested one slice ahead
+    bf16x8 radd[2], rnext[2];
+    auto row_of = [&](int mf, int it) { return row_base + mf * 16 + it * 8 + rin; };
+    auto load_rows = [&](int mf, bf16x8 (&dst)[2]) {
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int row = it * 8 + (lane >> 3);
-        const int c8 = (lane & 7) * 8;
-        const int gm = row0 + row, gn = col0 + c8;
-        if (gm >= p.M || gn >= p.N) continue;
-        const float* sp = st + row * 64 + c8;
-        if (gn + 8 <= p.N && vec_ok) {
-            f32x4 v0 = *(const f32x4*)sp, v1 = *(const f32x4*)(sp + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            epilogue_row8<EPI>(p, gm, gn, v);
-        } else {
-            for (int e = 0; e < 8 && gn + e < p.N; e++) epilogue_scalar<EPI>(p, gm, gn + e, sp[e]);
+        for (int it = 0; it < 2; it++) {
+            const int gm = min(row_of(mf, it), p.M - 1);
+            if (EPI == EPI_PATCH) dst[it] = *(const bf16x8*)(p.res + (int64_t)(1 + gm % p.group) * p.ldr + gn);
+            else dst[it] = *(const bf16x8*)(p.res + (int64_t)gm * p.ldr + gn);
         }
+    };
+    constexpr bool PRE = ADD_ROWS || EPI == EPI_PATCH;
+    if (PRE && vec_ok) load_rows(0, radd);
+#pragma unroll
+    for (int mf = 0; mf < 8; mf++) {
+        char* buf = stg + (mf & 1) * 2048;
+        stage_slice<EPI>(acc[mf], bias_f, scale_f, has_bias, buf, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (PRE && vec_ok && mf + 1 < 8) load_rows(mf + 1, rnext);
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int r = it * 8 + rin;
+            const int gm = row_of(mf, it);
+            const bf16x8 v = read_chunk(buf, r, c);
+            if (gm >= p.M || gn >= p.N) continue;
+            int64_t orow = gm;
+            if (EPI == EPI_PATCH) { const int t = gm / p.group; orow = (int64_t)t * (p.group + 1) + 1 + (gm - t * p.group); }
+            if (vec_ok) {
+                if (EPI == EPI_F32) {
+                    float* cp = (float*)p.C + orow * p.ldc + gn;
+                    *(f32x4*)cp = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+                    *(f32x4*)(cp + 4) = f32x4{bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7])};
+                } else if (PRE) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(radd[it][e]) + bf2f(v[e]));
+                    *(bf16x8*)((bf16*)p.C + orow * p.ldc + gn) = o;
+                } else {
+                    *(bf16x8*)((bf16*)p.C + orow * p.ldc + gn) = v;
+                }
+            } else {                                          // ragged N or unaligned rows: element by element
+                for (int e = 0; e < 8 && gn + e < p.N; e++) {
+                    float x = bf2f(v[e]);
+                    if (ADD_ROWS) x = bf2f(p.res[(int64_t)gm * p.ldr + gn + e]) + x;
+                    if (EPI == EPI_PATCH) x = x + bf2f(p.res[(int64_t)(1 + gm % p.group) * p.ldr + gn + e]);
+                    if (EPI == EPI_F32) ((float*)p.C)[orow * p.ldc + gn + e] = x;
+                    else ((bf16*)p.C)[orow * p.ldc + gn + e] = f2bf(x);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (PRE) { radd[0] = rnext[0]; radd[1] = rnext[1]; }
     }
 }
 
@@ -127,7 +262,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     const int schunk = (lane & 3) ^ ((srow >> 3) << 1);
     uint32_t qA[2];           // [mh]   offsets used by phases 2..8 (may already be the NEXT tile's); piece e = 1 is 64 B on
     uint32_t qB[2];           // [nh]
-    uint32_t p1A;             // U3 (A mh=1) of the tile being computed, for phase 1
     auto make_ptrs = [&](int m0, int n0) {
         // sub-tiles 2*wave and 2*wave + 1 are the two k-halves (ksub 0 / 1) of the same 16 rows
 #pragma unroll
@@ -150,33 +284,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     const int lane_off = lrow * 64 + (((lane >> 4) ^ ((lrow >> 3) << 1)) * 16);
     const int a_sub = wm * 8 * 1024 + lane_off;          // + (i*2 + ksub) * 1024
     const int b_sub = wn * 4 * 1024 + lane_off;          // + (j*2 + ksub) * 1024
-    float* st = (float*)(smem + LDS_MAIN2) + wave * 1024;
+    char* stg = smem + LDS_MAIN2 + wave * 4096;       // epilogue: two 2 KiB bf16 slices per wave
 
     f32x4 acc[8][4];
-    bf16x8 ra0[4][2], ra1[4][2];      // A fragments [i][ksub]: mh = 0 lives in ra0, mh = 1 in ra1
-    bf16x8 rbx[2][2], rby[2][2];      // B fragments [j][ksub]: the two halves swap registers every K-tile
+    bf16x8 ra[4][2];          // A fragments of the current quadrant row: [i][ksub]
+    bf16x8 rb[2][2][2];       // B fragments: [nh][j][ksub]
 
-#define READ_A(dst, buf, unit)                                                                  \
+#define READ_A(buf, unit)                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
-        dst[i][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + a_sub + (i * 2 + ks) * 1024);
-#define READ_B(dst, buf, unit)                                                                  \
+        ra[i][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + a_sub + (i * 2 + ks) * 1024);
+#define READ_B(buf, unit, nh)                                                                   \
     _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
-        dst[j][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024);
-    // one phase: operands of THIS phase were read a phase ago (retired by the lgkmcnt(0)); the reads for the NEXT
-    // phase and this phase's two DMA pieces are issued ahead of the 16 MFMAs and complete underneath them
-#define PHASE(mh, nh, RA, RB, PREFETCH, DMA)                                                    \
-    WAIT_LGKM0();                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-    PREFETCH;                                                                                   \
+        rb[nh][j][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024);
+    // a phase = a memory slot (fragment reads of this phase, one unit's two DMA pieces, the counted wait) and a
+    // matrix slot (16 MFMAs), each closed by s_barrier.  Waves 4..7 run one slot behind waves 0..3, so on every
+    // SIMD one wave's matrix slot runs beside its partner's memory slot.
+#define MEM_SLOT(READS, DMA, WAIT)                                                              \
+    READS;                                                                                      \
     DMA;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (WAIT) WAIT_VM8();                                                                       \
+    __builtin_amdgcn_s_barrier();
+#define MFMA_SLOT(mh, nh)                                                                       \
+    WAIT_LGKM0();                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_setprio(1);                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int i = 0; i < 4; i++) \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                           \
-            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(RA[i][ks], RB[j][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
+            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[nh][j][ks], ra[i][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                          \
-    WAIT_VM8();                                                                                 \
     __builtin_amdgcn_s_barrier();
 
     int t_cur = blockIdx.x;
@@ -184,12 +321,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     int m0, n0;
     tile_origin(t_cur, m0, n0);
     make_ptrs(m0, n0);
-    // ---- cold start (first tile of this workgroup only): K-tile 0 complete, U0..U2 of K-tile 1 in flight ----
+    // ---- cold start (first tile of this workgroup only): K-tile 0 and U0, U1 of K-tile 1 issued, U0/U1 of K-tile 0 landed
     dma(p.A, qA[0], 0, 0, 0); dma(p.W, qB[0], 0, 0, 1); dma(p.W, qB[1], 0, 0, 2); dma(p.A, qA[1], 0, 0, 3);
-    dma(p.A, qA[0], 1, 1, 0); dma(p.W, qB[0], 1, 1, 1); dma(p.W, qB[1], 1, 1, 2);
-    WAIT_VM6();
+    dma(p.A, qA[0], 1, 1, 0); dma(p.W, qB[0], 1, 1, 1);
+    WAIT_VM0();
     __builtin_amdgcn_s_barrier();
-    READ_A(ra0, 0, 0); READ_B(rbx, 0, 1);
 
     while (true) {
 #pragma unroll
@@ -198,35 +334,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int t_next = t_cur + gridDim.x;
         const bool has_next = t_next < ntiles;
+#ifdef CR_DIAG_STAMPS
+        uint64_t* dbg = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + (t_cur / gridDim.x)) * 4;
+        const bool stamp = p.scale && (wave & 3) == 0 && lane == 0 && (t_cur / gridDim.x) < 32;
+        if (stamp) dbg[0] = __builtin_amdgcn_s_memtime();
+#endif
+        if (wm) __builtin_amdgcn_s_barrier();                  // waves 4..7 start one slot late
 
         for (int kt = 0; kt < nk; kt += 2) {
-            p1A = qA[1];
-            int k2 = kt + 2;                                   // K-tile staged by phases 2..5 (and k2 + 1 by 6..8)
-            PHASE(0, 0, ra0, rbx, READ_B(rby, 0, 2), dma(p.A, p1A, kt + 1, 1, 3));
+            int k2 = kt + 2;                                   // K-tile staged by phases 3..6 (and k2 + 1 by 7, 8, 1', 2')
+            // first pair of a tile: everything phases 1..5 read landed before the epilogue of the previous tile (its
+            // stores made the compiler drain vmcnt), so slots 1..4 do not wait -- a counted wait there would sit on
+            // the in-order counter until the previous tile's output stores are acknowledged
+            const bool wt = kt != 0;
+            MEM_SLOT(READ_B(0, 1, 0); READ_A(0, 0), dma(p.W, qB[1], kt + 1, 1, 2), wt);
+            MFMA_SLOT(0, 0);
+            MEM_SLOT(READ_B(0, 2, 1), dma(p.A, qA[1], kt + 1, 1, 3), wt);
+            MFMA_SLOT(0, 1);
             if (k2 >= nk) {                                    // last pair: the look-ahead belongs to the next tile
                 if (has_next) { int nm0, nn0; tile_origin(t_next, nm0, nn0); make_ptrs(nm0, nn0); k2 = 0; }
-                else k2 = nk - 2;                              // nothing follows: re-load dead units with valid addresses
+                else k2 = nk - 2;                              // nothing follows: re-load dead units with the bytes they hold
             }
-            PHASE(0, 1, ra0, rby, READ_A(ra1, 0, 3), dma(p.A, qA[0], k2, 0, 0));
-            PHASE(1, 1, ra1, rby, READ_A(ra0, 1, 0), dma(p.W, qB[0], k2, 0, 1));
-            PHASE(1, 0, ra1, rbx, READ_B(rby, 1, 1), dma(p.W, qB[1], k2, 0, 2));
-            PHASE(0, 0, ra0, rby, READ_B(rbx, 1, 2), dma(p.A, qA[1], k2, 0, 3));
-            PHASE(0, 1, ra0, rbx, READ_A(ra1, 1, 3), dma(p.A, qA[0], k2 + 1, 1, 0));
-            PHASE(1, 1, ra1, rbx, READ_A(ra0, 0, 0), dma(p.W, qB[0], k2 + 1, 1, 1));
-            PHASE(1, 0, ra1, rby, READ_B(rbx, 0, 1), dma(p.W, qB[1], k2 + 1, 1, 2));
+            MEM_SLOT(READ_A(0, 3), dma(p.A, qA[0], k2, 0, 0), wt);
+            MFMA_SLOT(1, 1);
+            MEM_SLOT(, dma(p.W, qB[0], k2, 0, 1), wt);
+            MFMA_SLOT(1, 0);
+            MEM_SLOT(READ_B(1, 1, 0); READ_A(1, 0), dma(p.W, qB[1], k2, 0, 2), true);
+            MFMA_SLOT(0, 0);
+            MEM_SLOT(READ_B(1, 2, 1), dma(p.A, qA[1], k2, 0, 3), true);
+            MFMA_SLOT(0, 1);
+            MEM_SLOT(READ_A(1, 3), dma(p.A, qA[0], k2 + 1, 1, 0), true);
+            MFMA_SLOT(1, 1);
+            MEM_SLOT(, dma(p.W, qB[0], k2 + 1, 1, 1), true);
+            MFMA_SLOT(1, 0);
         }
+#ifdef CR_DIAG_STAMPS
+        if (stamp) dbg[1] = __builtin_amdgcn_s_memtime();
+#endif
+        if (!wm) __builtin_amdgcn_s_barrier();                 // waves 0..3 wait out the partners' last matrix slot
+        WAIT_VM0();
+#ifdef CR_DIAG_STAMPS
+        if (stamp) dbg[2] = __builtin_amdgcn_s_memtime();
+#endif       // the look-ahead (K-tile 0 and U0, U1 of K-tile 1 of the next tile) has landed: slots 1..4 rely on it
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----
-#pragma unroll
-        for (int mf = 0; mf < 8; mf++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) st[((lane >> 4) * 4 + e) * 64 + j * 16 + (lane & 15)] = acc[mf][j][e];
-            __builtin_amdgcn_wave_barrier();
-            epilogue_rows16<EPI>(p, st, m0 + wm * 128 + mf * 16, n0 + wn * 64, lane);
-            __builtin_amdgcn_wave_barrier();
-        }
+        epilogue_tile<EPI>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
+#ifdef CR_DIAG_STAMPS
+        if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();
+#endif
         if (!has_next) break;
         t_cur = t_next;
         tile_origin(t_cur, m0, n0);
