@@ -43,7 +43,11 @@
 //   * the main loop never drains vmcnt to 0; barriers are raw s_barrier (a __syncthreads() would drain the DMA).
 //   * measured nulls (kept out of the code): a second barrier at the start of each lock-stepped phase (-2..3 %),
 //     write-through (sc1) output stores (-1 %), spreading the workgroups' start times over 8-32 us (+-0: the
-//     epilogue's stores are bound per CU, not by the chip), skipping the output stores entirely (10 % at K = 1024).
+//     epilogue's stores are bound per CU, not by the chip), skipping the output stores entirely (10 % at K = 1024),
+//     evening the memory slots out to 8/4/8/4 reads by fetching the next K-tile's nh = 0 fragment in slots 4 and 8
+//     into the idle B register set (-1..5 %), one barrier per phase with the late group's barrier moved between its
+//     memory and matrix slot (-5 % at large K).  Per-slot stamps: every slot takes ~300 clocks whatever it holds
+//     (0..12 reads), against 256 of MFMA issue: what is left is the fixed cost of a barrier-closed slot.
 //
 // Persistent: <= 256 workgroups (one per CU) walk the tile list.  The look-ahead of the schedule runs straight
 // through a tile boundary: in the last K-tile pair of a tile, phases 3..8 already stage K-tile 0 and U0/U1 of
