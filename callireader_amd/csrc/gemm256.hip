@@ -168,7 +168,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = f2bf(rbf(silu(bf2f(gt[e]))) * bf2f(up[e]));
-            if (gm < p.M && gno + 8 <= p.N / 2) *(bf16x8*)((bf16*)p.C + (int64_t)gm * p.ldc + gno) = o;
+            if (gm < p.M && gno + 8 <= p.N / 2) __builtin_nontemporal_store(o, (bf16x8*)((bf16*)p.C + (int64_t)gm * p.ldc + gno));
             __builtin_amdgcn_wave_barrier();
         }
         return;
@@ -212,9 +212,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(radd[it][e]) + bf2f(v[e]));
-                    *(bf16x8*)((bf16*)p.C + orow * p.ldc + gn) = o;
+                    __builtin_nontemporal_store(o, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 } else {
-                    *(bf16x8*)((bf16*)p.C + orow * p.ldc + gn) = v;
+                    __builtin_nontemporal_store(v, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 }
             } else {                                          // ragged N or unaligned rows: element by element
                 for (int e = 0; e < 8 && gn + e < p.N; e++) {
