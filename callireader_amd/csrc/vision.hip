@@ -5,6 +5,8 @@
 //   LN1 -> GEMM qkv(+bias) -> flash attention -> GEMM proj(+bias, *ls1, +x, in place)
 //   LN2 -> GEMM fc1(+bias, GELU) -> GEMM fc2(+bias, *ls2, +x, in place)
 // The residual stream x lives in the caller's output buffer; nothing is copied.
+#include <stdlib.h>
+
 #include "attention.hpp"
 #include "ctx.hpp"
 #include "misc.hpp"
@@ -14,9 +16,9 @@ static constexpr int VIT_CHUNK = 63;   // 63*1025 rows = 253 row-tiles of 256: x
 // Chunks of 16k-1 tiles (63, 47, 31, 15) put ceil(rows/256) * {4,12,16} GEMM tiles just under a whole number of
 // 256-CU rounds; e.g. 32 tiles are run as 31 + 1 (129 row-tiles -> 125: the 129th held 32 rows and cost a round).
 static int next_chunk(int remaining) {
-    if (remaining >= 63) return 63;
-    for (int c : {47, 31, 15}) if (remaining >= c) return c;
-    return remaining;
+    static const int cap = [] { const char* e = getenv("CR_VIT_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 && v < VIT_CHUNK ? v : VIT_CHUNK; }();   // tuning aid
+    for (int c : {63, 47, 31, 15}) if (c <= cap && remaining >= c) return c;
+    return remaining < cap ? remaining : cap;
 }
 static constexpr int C1 = 1024, C3 = 3072, FF = 4096, TOK = 1025, KPAD = 640;
 
