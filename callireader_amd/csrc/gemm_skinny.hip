@@ -5,6 +5,8 @@
 //   * one workgroup owns 16 rows of W (one v_mfma_f32_16x16x32_bf16 A-tile) over the whole K;
 //     its WAVES waves split K into contiguous slices, so N/16 * WAVES waves keep enough loads in flight
 //     to cover HBM latency (WAVES = 8 for N <= 8192, 4 above);
+//   * RT = 16-row weight tiles per wave (4 where N >= 16384 and M > 16): the X fragments are loaded once per RT
+//     tiles; X comes from L2 but through the same per-CU load path as W, and at M = 32 it is 2 x the W bytes at RT = 1;
 //   * per k-step a lane loads 16 B of W (row n = lane&15, k = 8*(lane>>4) .. +7) and 16 B of each X tile,
 //     UNROLL k-steps of loads are issued before the first MFMA;
 //   * accumulator = C^T tile [16 n][16 m] per X tile, so the lane holds 4 consecutive n of one m;
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
 #pragma unroll
     for (int t = 0; t < MT; t++) xp[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq;
 
-    constexpr int UR = RT == 1 ? UNROLL : UNROLL / 2;
+    constexpr int UR = UNROLL / RT;
     f32x4 acc[RT][MT];
 #pragma unroll
     for (int r = 0; r < RT; r++)
@@ -128,7 +130,9 @@ int launch_mt(const GemmParams& p, hipStream_t stream) {
 template <int EPI>
 int launch_w(const GemmParams& p, hipStream_t stream) {
     if (p.N <= 8192 && p.K % 256 == 0) return launch_mt<EPI, 8, 1>(p, stream);
-    if (p.N >= 16384 && p.M > 16) return launch_mt<EPI, 4, 2>(p, stream);      // two row tiles per wave: half the X re-reads
+    // four row tiles per wave where N still fills the chip: a quarter of the X re-reads (w1|w3 at M = 32: 81 us with
+    // two tiles, 63 us with four, 71 us with eight -- eight leaves 224 workgroups for 256 CUs)
+    if (p.N >= 16384 && p.M > 16) return launch_mt<EPI, 4, 4>(p, stream);
     return launch_mt<EPI, 4, 1>(p, stream);
 }
 

@@ -275,13 +275,13 @@ def test_gemm_skinny_swiglu_and_row_independence(E):
     assert torch.equal(one[0], out[4]) and torch.equal(big[9 + 4], out[4])
 
 
-def test_gemm_skinny_two_row_tiles_path(E):
-    """N >= 16384 with M > 16 uses two weight row-tiles per wave; results must equal the one-tile path row for row."""
+def test_gemm_skinny_multi_row_tile_path(E):
+    """N >= 16384 with M > 16 uses four weight row-tiles per wave; results must equal the one-tile path row for row."""
     g = torch.Generator().manual_seed(41)
     N, K = 16400, 512                      # ragged N (like the 92553-row LM head)
     W = bf(_rand((N, K), g, 0.05)).to(dev())
     A = bf(_rand((40, K), g)).to(dev())
-    big = E.op_gemm(6, A, W, out_dtype=torch.float32)                    # M = 40 -> RT = 2
+    big = E.op_gemm(6, A, W, out_dtype=torch.float32)                    # M = 40 -> RT = 4
     small = E.op_gemm(6, A[:9].contiguous(), W, out_dtype=torch.float32)  # M = 9  -> RT = 1
     torch.cuda.synchronize()
     assert torch.equal(big[:9], small)
