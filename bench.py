@@ -97,7 +97,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--pages', type=int, default=32, help='pages per GPU per step (all pages of a step decode as one batch)')
+    ap.add_argument('--pages', type=int, default=64, help='pages per GPU per step (all pages of a step decode as one batch; 64 = the most rows the decode kernels take)')
     ap.add_argument('--new-tokens', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-vit-extra', action='store_true')

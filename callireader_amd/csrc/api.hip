@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include "attention.hpp"
+#include <stdlib.h>
+
 #include "ctx.hpp"
 #include "misc.hpp"
 #include "norm.hpp"
@@ -83,6 +85,7 @@ int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     cr_ctx* c = new cr_ctx();
     c->device = device;
     c->d = *desc;
+    { const char* e = getenv("CR_NO_SLICED_DECODE"); c->no_sliced_decode = e && atoi(e) != 0; }
     c->scratch_bytes = 1 << 20;
     if (hipMalloc((void**)&c->scratch, c->scratch_bytes) != hipSuccess) { delete c; return cr_fail(CR_ERR_NOMEM, "scratch"); }
     hipMemset(c->scratch, 0, c->scratch_bytes);

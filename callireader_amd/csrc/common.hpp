@@ -82,6 +82,7 @@ enum GemmEpi {
     EPI_SWIGLU = 4,   // bf16(bf16(silu(bf16(g))) * bf16(u)), W rows interleaved [8 gate | 8 up]
     EPI_PATCH = 5,    // patch-embed: bf16(bf16(acc + bias) + pos[1 + m % G]) -> row (m / G) * (G + 1) + 1 + m % G
     EPI_F32 = 6,      // float(bf16(acc + bias))                            (logits: bf16 GEMM then .float())
+    EPI_PARTIAL = 7,  // decode only (M <= 64): fp32 partial sums [S][M][N] of S K-slices, no bias; the consumer kernel sums them
 };
 
 struct GemmParams {
@@ -97,3 +98,5 @@ struct GemmParams {
 };
 
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
+// K-slices of the EPI_PARTIAL decode GEMM for an [N, K] weight (depends on N and K only, never on M); 0 = unsupported
+int gemm_partial_splits(int N, int K);

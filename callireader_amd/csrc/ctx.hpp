@@ -20,6 +20,7 @@ struct cr_ctx {
     int device = 0;
     cr_model_desc d{};
     bool finalized = false;
+    bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
     std::unordered_map<std::string, DevTensor> w;
     // workspace
     char* ws = nullptr;

@@ -13,6 +13,9 @@
 //   * partial tiles of the waves are summed through LDS in a fixed order (bitwise reproducible, and a row's
 //     result does not depend on how many other rows are in the batch);
 //   * epilogues: store / +residual / SwiGLU (rows [8 gate | 8 up] of one tile -> 8 outputs) / fp32 logits.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -27,8 +30,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * 16 * RT;
     const int kq = (lane >> 4) * 8;
-    const int ksteps = p.K / (32 * WAVES);            // k-steps of 32 per wave
-    const int kbase = wave * ksteps * 32;
+    // gridDim.y K-slices (EPI_PARTIAL; 1 otherwise), each split over the waves
+    const int ksteps = p.K / (32 * WAVES * (int)gridDim.y);            // k-steps of 32 per wave
+    const int kbase = ((int)blockIdx.y * WAVES + wave) * ksteps * 32;
     const bf16* wp[RT];
 #pragma unroll
     for (int r = 0; r < RT; r++) wp[r] = p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq;
@@ -90,6 +94,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         red[0][t][n][m] = s;       // own element only: no hazard with other threads' reads
     }
     __syncthreads();
+    if (EPI == EPI_PARTIAL) {
+        float* out = (float*)p.C + (int64_t)blockIdx.y * p.M * p.ldc;
+        for (int idx = tid; idx < RT * MT * 256; idx += WAVES * 64) {
+            const int t = idx >> 8, n = idx & 15, m = (idx >> 4) & 15;
+            const int gm = (t % MT) * 16 + m, gn = n0 + (t / MT) * 16 + n;
+            if (gm < p.M && gn < p.N) out[(int64_t)gm * p.ldc + gn] = red[0][t][n][m];
+        }
+        return;
+    }
     if (EPI == EPI_SWIGLU) {
         for (int idx = tid; idx < RT * MT * 128; idx += WAVES * 64) {
             const int q = idx >> 7, j = idx & 7, m = (idx >> 3) & 15;
@@ -114,9 +127,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
 }
 
 template <int EPI, int WAVES, int RT>
-int launch_mt(const GemmParams& p, hipStream_t stream) {
+int launch_mt(const GemmParams& p, hipStream_t stream, int splits = 1) {
     const int mt = (p.M + 15) / 16;
-    const dim3 grid((p.N + 16 * RT - 1) / (16 * RT)), block(WAVES * 64);
+    const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), splits), block(WAVES * 64);
     switch (mt) {
         case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 1, RT>), grid, block, 0, stream, p); break;
         case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 2, RT>), grid, block, 0, stream, p); break;
@@ -136,10 +149,46 @@ int launch_w(const GemmParams& p, hipStream_t stream) {
     return launch_mt<EPI, 4, 1>(p, stream);
 }
 
+// EPI_PARTIAL geometry: 8 waves x RT row tiles per workgroup, S K-slices, so that a workgroup re-reads X (from L2,
+// through the same per-CU load path as its W rows from HBM) once per 16*RT weight rows instead of once per 16: at
+// M = 32 / 64 the one-tile kernel moves 2x / 4x as many X bytes as W bytes (wqkv 1.65 / 1.12 TB/s of weights).
+// The K-slices restore the workgroup count that the taller workgroups lose.
+struct PartialGeom { int rt, splits; };
+PartialGeom partial_geom(int N, int K) {
+    const int units = K / 256;                 // 8 waves x 32: the K granule of one workgroup
+    if (K % 256 != 0 || units == 0) return {0, 0};
+    {   // tuning aid: CR_PARTIAL_GEOM="N,K,rt,splits" pins one shape's geometry
+        static const char* e = getenv("CR_PARTIAL_GEOM");
+        int en, ek, ert, es;
+        if (e && sscanf(e, "%d,%d,%d,%d", &en, &ek, &ert, &es) == 4 && en == N && ek == K && ert >= 1 && ert <= 4 &&
+            N % (16 * ert) == 0 && es >= 1 && units % es == 0)
+            return {ert, es};
+    }
+    // cost of a launch ~ rounds of 256 workgroups x (bytes per workgroup: (W rows + X rows at a nominal M = 32) / slices,
+    // + a fixed per-workgroup share).  Measured at M = 32 / 64 (us): wqkv (3,2) 18.8 / 22.7, (4,8) 19.7 / 29.8,
+    // (4,4) 20.3 / 29.0; wo (4,4) 14.2 / 16.8, (2,2) 14.9 / 19.2, (4,8) 14.8 / 20.6; w2 (4,4) 32.4 / 39.4, (4,7) 36.8 / 48.0,
+    // (2,2) 40.4 / 53.0 -- against 30.4 / 45.1, 17.3 / 25.3 and 53.8 / 81.9 for the one-tile kernel.
+    PartialGeom best{0, 0};
+    double best_cost = 1e30;
+    for (int rt : {4, 3, 2, 1}) {
+        if (N % (16 * rt) != 0) continue;
+        const int nb = N / (16 * rt);
+        for (int s : {1, 2, 4, 7, 8}) {
+            if (units % s != 0) continue;
+            const double cost = (double)((nb * s + 255) / 256) * ((rt + 2.0) / s + 0.6) + 0.02 * s;   // + the partial-sum traffic
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = {rt, s}; }
+        }
+    }
+    return best;
+}
+
 }  // namespace
+
+int gemm_partial_splits(int N, int K) { return partial_geom(N, K).splits; }
 
 bool gemm_skinny_supported(int epi, const GemmParams& p) {
     if (p.M > 64 || p.K % 128 != 0) return false;
+    if (epi == EPI_PARTIAL) return p.bias == nullptr && partial_geom(p.N, p.K).splits > 0;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;
     if (epi == EPI_SWIGLU) return p.N % 16 == 0;
@@ -152,6 +201,16 @@ int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream) {
         case EPI_RES: return launch_w<EPI_RES>(p, stream);
         case EPI_SWIGLU: return launch_w<EPI_SWIGLU>(p, stream);
         case EPI_F32: return launch_w<EPI_F32>(p, stream);
+        case EPI_PARTIAL: {
+            const PartialGeom g = partial_geom(p.N, p.K);
+            switch (g.rt) {
+                case 4: return launch_mt<EPI_PARTIAL, 8, 4>(p, stream, g.splits);
+                case 3: return launch_mt<EPI_PARTIAL, 8, 3>(p, stream, g.splits);
+                case 2: return launch_mt<EPI_PARTIAL, 8, 2>(p, stream, g.splits);
+                case 1: return launch_mt<EPI_PARTIAL, 8, 1>(p, stream, g.splits);
+            }
+            return CR_ERR_ARG;
+        }
     }
     return CR_ERR_ARG;
 }

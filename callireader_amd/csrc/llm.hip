@@ -6,6 +6,8 @@
 // Per layer: RMSNorm -> GEMM wqkv -> RoPE + split (q to a dense buffer, k/v straight into the cache)
 //            -> flash attention (causal GQA in prefill; 4 heads of a KV group as the "rows" in decode)
 //            -> GEMM wo (+x in place) -> RMSNorm -> GEMM w1|w3 with SwiGLU epilogue -> GEMM w2 (+x in place).
+// Decode (<= 64 rows): wqkv / wo / w2 leave fp32 K-slices that RoPE-split and a fused residual-add + RMSNorm sum up.
+#include <algorithm>
 #include <vector>
 
 #include "attention.hpp"
@@ -101,17 +103,34 @@ __global__ __launch_bounds__(128) void rope_split_kernel(const bf16* __restrict_
                                                          const bf16* __restrict__ sinT, bf16* __restrict__ q_out,
                                                          bf16* __restrict__ kc, bf16* __restrict__ vc, int pos0, int seq0,
                                                          const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
-                                                         const int32_t* __restrict__ row_pos, int max_tokens) {
+                                                         const int32_t* __restrict__ row_pos, int max_tokens,
+                                                         const float* __restrict__ part, int splits) {
+    // part != nullptr (decode): the wqkv output arrives as `splits` fp32 K-slices [s][rows][QKV]; their sum in slice
+    // order, rounded once, is the bf16 linear output the reference rotates
     const int row = blockIdx.x, grp = blockIdx.y;
     const int slot = threadIdx.x >> 4, c = threadIdx.x & 15;
     if (slot >= 6) return;
     const int seq = seqs ? seqs[row] : seq0;
     const int pos = row_pos ? row_pos[row] : (lens ? lens[seq] : pos0 + row);
-    const bf16* src = qkv + (int64_t)row * QKV + (grp * 6 + slot) * HD;
-    const bf16x8 x = *(const bf16x8*)(src + c * 8);
+    const int64_t col0 = (int64_t)(grp * 6 + slot) * HD;
+    auto chunk = [&](int cc) -> bf16x8 {
+        if (!part) return *(const bf16x8*)(qkv + (int64_t)row * QKV + col0 + cc * 8);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; s++) {
+            const f32x4* pp = (const f32x4*)(part + ((int64_t)s * gridDim.x + row) * QKV + col0 + cc * 8);
+            const f32x4 v0 = pp[0], v1 = pp[1];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { a[e] += v0[e]; a[4 + e] += v1[e]; }
+        }
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; e++) r[e] = f2bf(a[e]);
+        return r;
+    };
+    const bf16x8 x = chunk(c);
     bf16x8 y;
     if (slot < 5) {
-        const bf16x8 xp = *(const bf16x8*)(src + ((c + 8) & 15) * 8);
+        const bf16x8 xp = chunk((c + 8) & 15);
         const bf16x8 cs = *(const bf16x8*)(cosT + (int64_t)pos * HD + c * 8);
         const bf16x8 sn = *(const bf16x8*)(sinT + (int64_t)pos * HD + c * 8);
         const float sign = c < 8 ? -1.0f : 1.0f;           // rotate_half: (-x2, x1)
@@ -228,15 +247,25 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
     const bf16 *cosT = W(c, "rope.cos"), *sinT = W(c, "rope.sin");
     if (!cosT || !sinT) return CR_ERR_STATE;
     const int64_t per_layer = (int64_t)kv->n_seqs * NKV * kv->max_tokens * HD;
+    // decode (M <= 64): wqkv, wo and w2 run as K-sliced partial-sum GEMMs (gemm_skinny.hip: tall workgroups re-read X
+    // once per 64 weight rows); the slices are summed by the kernel that consumes the result anyway -- RoPE/split for
+    // wqkv, the residual add fused with the NEXT RMSNorm for wo and w2 -- in slice order, so a row's result is the same
+    // whatever it is batched with.
+    const int s_qkv = decode ? gemm_partial_splits(QKV, D) : 0, s_o = decode ? gemm_partial_splits(D, D) : 0,
+              s_2 = decode ? gemm_partial_splits(D, ff) : 0;
+    const bool sliced = decode && M <= 64 && s_qkv > 0 && s_o > 0 && s_2 > 0 && !c->no_sliced_decode;
+    float* pbuf = sliced ? ar.take<float>((size_t)std::max(s_qkv * QKV, std::max(s_o, s_2) * D) * M) : nullptr;
     for (int l = 0; l < c->d.llm_layers; l++) {
         LayerW w;
         CR_TRY(layer_weights(c, l, w));
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
-        CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
-        CR_TRY(gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
+        if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
+        if (sliced) CR_TRY(gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st));
+        else CR_TRY(gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
         hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
-                           decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens);
+                           decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens,
+                           (const float*)(sliced ? pbuf : nullptr), s_qkv);
         AttnParams ap{};
         ap.K = kc; ap.V = vc; ap.Q = q; ap.O = ao;
         ap.k_bs = ap.v_bs = (int64_t)NKV * kv->max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)kv->max_tokens * HD;
@@ -258,10 +287,26 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             ap.nsplit = nsplit; ap.part_ml = part; ap.part_o = part + (size_t)M * NKV * nsplit * (NH / NKV) * 2;
             if (launch_flash_attn_split(ap, HD, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
         }
-        CR_TRY(gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
-        CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
+        if (sliced) {
+            CR_TRY(gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st));
+            CR_TRY(launch_add_rmsnorm(x, pbuf, s_o, M, w.fn, h, c->d.rms_eps, st));
+        } else {
+            CR_TRY(gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+            CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
+        }
         CR_TRY(gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
-        CR_TRY(gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
+        if (sliced) {
+            CR_TRY(gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st));
+            const bf16* next_norm = nullptr;             // the last layer's sum only lands in x: the caller norms what it needs
+            if (l + 1 < c->d.llm_layers) {
+                LayerW wn;
+                CR_TRY(layer_weights(c, l + 1, wn));
+                next_norm = wn.an;
+            }
+            CR_TRY(launch_add_rmsnorm(x, pbuf, s_2, M, next_norm, h, c->d.rms_eps, st));
+        } else {
+            CR_TRY(gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
+        }
     }
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -269,7 +314,8 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
 
 size_t layers_ws(cr_ctx* c, int M, int nsplit = 0) {
     const size_t ff = (size_t)WT(c, "derived.w13.0")->shape[0] / 2;
-    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + 8192;
+    const size_t sliced = nsplit > 0 && M <= 64 ? (size_t)8 * QKV * M * 4 : 0;       // K-slice partial sums of the decode GEMMs
+    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + 8192;
 }
 
 }  // namespace

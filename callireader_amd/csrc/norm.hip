@@ -96,7 +96,51 @@ __global__ __launch_bounds__(256) void rmsnorm4096_kernel(const NormParams p) {
     store16(p.out + row * p.ld_out + tid * 16, y);
 }
 
+// residual add of a K-sliced GEMM result + the next RMSNorm (decode): modeling_internlm2.py:655-669
+//   hidden = residual + attention/ffn output (both bf16) ; hidden -> norm
+__global__ __launch_bounds__(256) void add_rmsnorm4096_kernel(bf16* __restrict__ xio, const float* __restrict__ part, int splits,
+                                                             int64_t rows, const bf16* __restrict__ gamma, bf16* __restrict__ out,
+                                                             float eps) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    float x[16], a[16];
+    load16(xio + row * 4096 + tid * 16, x);
+#pragma unroll
+    for (int e = 0; e < 16; e++) a[e] = 0.f;
+    for (int s = 0; s < splits; s++) {
+        const f32x4* pp = (const f32x4*)(part + ((int64_t)s * rows + row) * 4096 + tid * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = pp[q];
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[q * 4 + e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = rbf(x[e] + rbf(a[e]));
+    store16(xio + row * 4096 + tid * 16, x);
+    if (!gamma) return;
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) ss += x[e] * x[e];
+    const float var = row_sum<256>(ss, red, tid) * (1.0f / 4096.0f);
+    const float rs = rsqrtf(var + eps);
+    float g[16], y[16];
+    load16(gamma + tid * 16, g);
+#pragma unroll
+    for (int e = 0; e < 16; e++) y[e] = g[e] * rbf(x[e] * rs);
+    store16(out + row * 4096 + tid * 16, y);
+}
+
 }  // namespace
+
+int launch_add_rmsnorm(bf16* x, const float* part, int splits, int64_t rows, const bf16* gamma, bf16* out, float eps, hipStream_t stream) {
+    if (rows <= 0) return CR_OK;
+    if (!x || !part || splits <= 0 || (gamma && !out)) return CR_ERR_ARG;
+    hipLaunchKernelGGL(add_rmsnorm4096_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, part, splits, rows, gamma, out, eps);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
 
 int launch_layernorm(const NormParams& p, int n, int mode, hipStream_t stream) {
     if (p.rows <= 0) return CR_OK;

@@ -15,3 +15,6 @@ struct NormParams {
 // mode 0: rows of n (1024 | 4096) bf16; mode 1: pixel-shuffle gather feeding mlp1's LayerNorm (n = 4096)
 int launch_layernorm(const NormParams& p, int n, int mode, hipStream_t stream);
 int launch_rmsnorm(const NormParams& p, int n, hipStream_t stream);
+// decode: x[row] = bf16(x[row] + bf16(sum_s part[s][row])) for rows of 4096 (part = fp32 [S][rows][4096], the K-slices of
+// an EPI_PARTIAL GEMM, summed in slice order), then, when gamma is given, out[row] = RMSNorm(x[row]) * gamma
+int launch_add_rmsnorm(bf16* x, const float* part, int splits, int64_t rows, const bf16* gamma, bf16* out, float eps, hipStream_t stream);

@@ -233,6 +233,8 @@ def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torc
     N = Wt.shape[0]
     ncols = n_out if n_out is not None else (N // 2 if epi == 4 else N)
     mrows = M if epi != 5 else (M // group) * (group + 1)
+    if epi == 7:                     # fp32 K-slice partial sums [S <= 8][M][N]; unused slabs stay zero
+        mrows, out_dtype = 8 * M, torch.float32
     Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
     B.check(B.lib.cr_op_gemm(epi | (kernel << 8), _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')

@@ -297,6 +297,25 @@ def test_gemm_skinny_multi_row_tile_path(E):
     torch.testing.assert_close(o_big.float(), rb(rb(torch.nn.functional.silu(gte)) * up), rtol=RTOL, atol=2e-2)
 
 
+@pytest.mark.parametrize('M,N,K', [(32, 6144, 4096), (40, 4096, 14336), (7, 4096, 4096), (64, 256, 512), (64, 6144, 4096)])
+def test_gemm_skinny_k_sliced_partials(E, M, N, K):
+    """Decode's wqkv / wo / w2: fp32 partial sums of K-slices (tall workgroups), summed by the consumer.  The slices
+    add up to the product, and a row's slices do not depend on the rows it is batched with."""
+    g = torch.Generator().manual_seed(M + N)
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.03)).to(dev())
+    part = E.op_gemm(7, A, W).reshape(8, M, N)
+    few = E.op_gemm(7, A[:5].contiguous(), W).reshape(8, 5, N)
+    torch.cuda.synchronize()
+    assert torch.equal(part[:, :5], few)
+    used = int((part.abs().amax(dim=(1, 2)) > 0).sum())
+    assert 1 <= used <= 8 and float(part[used:].abs().max() if used < 8 else 0) == 0.0
+    total = torch.zeros(M, N, device=dev())
+    for s_ in range(used):
+        total = total + part[s_]
+    torch.testing.assert_close(total, A.float() @ W.float().t(), rtol=1e-4, atol=2e-3)
+
+
 def test_gemm_rejects_bad_k(E):
     A = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
     W = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
