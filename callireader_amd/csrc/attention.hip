@@ -25,6 +25,17 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// two floats -> packed bf16 pair (RNE) with one v_cvt_pk_bf16_f32: the vector conversion is what selects the packed
+// instruction (two scalar casts compile to two conversions plus shifts); unpacking is integer so LLVM cannot fold the
+// rounding away
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_bf16(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float hi_bf16(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+
 template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
 template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
 
@@ -157,27 +168,32 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             }
         }
         // ---- scores: reference rounding, masking, online softmax (query = lane) ----
-        // bf16 rounding of a pair with one v_cvt_pk_bf16_f32 (RNE) + two unpack ops; masking only on tiles that need it
+        // A pair of scores is rounded to bf16 by ONE v_cvt_pk_bf16_f32 and stays packed until the exponentials; the
+        // row maximum is taken on the raw accumulators (rounding is monotonic, so max(round(s)) = round(max(s))) with
+        // v_max3_f32.  Masking only on tiles that need it.
         const bool need_mask = (kt * 64 + 64 > Sk) || (CAUSAL && kt * 64 + 63 > p.q_pos0 + qb * 128 + wave * 32);
-        float mloc = -INFINITY;
+        float mraw = -INFINITY;
+        unsigned spk[2][8];
         auto score_pass = [&](auto masked) {
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
-                    float s0, s1;
-                    round_pair_bf16(sacc[kb][e], sacc[kb][e + 1], s0, s1);
-                    if (DIV) round_pair_bf16(s0 * inv_div, s1 * inv_div, s0, s1);
+                    float s0 = sacc[kb][e], s1 = sacc[kb][e + 1];
                     if (decltype(masked)::value) {
                         const int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                         s0 = (key < Sk && (!CAUSAL || key <= qpos)) ? s0 : -INFINITY;
                         s1 = (key + 1 < Sk && (!CAUSAL || key + 1 <= qpos)) ? s1 : -INFINITY;
                     }
-                    sacc[kb][e] = s0; sacc[kb][e + 1] = s1;
-                    mloc = fmaxf(mloc, fmaxf(s0, s1));
+                    mraw = fmaxf(mraw, fmaxf(s0, s1));
+                    unsigned pk = pack_bf16(s0, s1);
+                    if (DIV) pk = pack_bf16(lo_bf16(pk) * inv_div, hi_bf16(pk) * inv_div);
+                    spk[kb][e >> 1] = pk;
                 }
         };
         if (need_mask) score_pass(std::true_type{}); else score_pass(std::false_type{});   // wave-uniform
+        float mloc = lo_bf16(pack_bf16(mraw, mraw));
+        if (DIV) mloc = lo_bf16(pack_bf16(mloc * inv_div, mloc * inv_div));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         // deferred rescale: while no row's maximum grows by more than 8 the reference point m_run stays (P <= e^8 keeps
         // bf16's relative precision) and the O / l rescale is skipped; the vote is wave-uniform
@@ -187,13 +203,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         const float alpha = rescale ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
         m_run = m_new;
         float psum = 0.f;
+        unsigned ppk[2][8];                                   // P as packed bf16 pairs: the PV B-operand, 4 dwords per fragment
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], LOG2E, -m2));
-                sacc[kb][e] = pe;
-                psum += pe;
+            for (int i = 0; i < 8; i++) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(lo_bf16(spk[kb][i]), LOG2E, -m2));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(hi_bf16(spk[kb][i]), LOG2E, -m2));
+                psum += p0 + p1;
+                ppk[kb][i] = pack_bf16(p0, p1);
             }
         l_run = l_run * alpha + psum;
         if (rescale) {
@@ -209,9 +227,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             if (kb == 1 && !two_blocks) break;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                bf16x8 pf;
-#pragma unroll
-                for (int e = 0; e < 8; e++) pf[e] = f2bf(sacc[kb][8 * s + e]);
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                const u32x4 pw = {ppk[kb][4 * s], ppk[kb][4 * s + 1], ppk[kb][4 * s + 2], ppk[kb][4 * s + 3]};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
                 for (int db = 0; db < DB; db++) {
                     const int chunk = ((db * 4) ^ v_sw) | v_clow;
