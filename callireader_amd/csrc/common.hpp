@@ -27,12 +27,14 @@ __device__ __forceinline__ float rbf(float x) {
     return __uint_as_float(u);
 }
 
-// (a, b) -> bf16-rounded (RNE) values as floats: the cast of the pair compiles to one v_cvt_pk_bf16_f32; unpacking
-// through integer ops keeps LLVM from folding the rounding away.  Deliberately NOT inline asm: as the first reader
-// of MFMA results an asm statement gets no MFMA->VALU wait states from hipcc (NaNs observed).
+// (a, b) -> bf16-rounded (RNE) values as floats.  The VECTOR conversion is what selects one v_cvt_pk_bf16_f32 for the
+// pair (two scalar casts compile to two conversions plus shifts); unpacking through integer ops keeps LLVM from
+// folding the rounding away.  Deliberately NOT inline asm: as the first reader of MFMA results an asm statement
+// gets no MFMA->VALU wait states from hipcc (NaNs observed).
 __device__ __forceinline__ void round_pair_bf16(float a, float b, float& ra, float& rb2) {
-    const bf16x2 v = {(bf16)a, (bf16)b};
-    const unsigned pk = __builtin_bit_cast(unsigned, v);
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 v2 = {a, b};
+    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
     ra = __uint_as_float(pk << 16);
     rb2 = __uint_as_float(pk & 0xffff0000u);
 }
