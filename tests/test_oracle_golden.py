@@ -169,3 +169,21 @@ def test_splice_asserts_and_values():
     assert out[0, 0].tolist() == [4.0, 5.0, 6.0, 7.0]
     with pytest.raises(AssertionError):
         generate.splice_embeddings(sd, torch.tensor([[1, 2]]), vit, None, img_context_token_id=7)
+
+
+def test_repetition_penalty_rule_matches_installed_transformers():
+    """The greedy loop as a whole stays unpinned (the reference's transformers 4.45.2 is not installed and the
+    installed release cannot drive the reference model), but the one piece of arithmetic in it can be pinned against
+    the library's own RepetitionPenaltyLogitsProcessor, whose rule has not changed since 4.45.2: every id already
+    generated (duplicates included) sees score/penalty if score > 0 else score*penalty, applied to the ORIGINAL score."""
+    lp = pytest.importorskip('transformers.generation.logits_process')
+    from oracle.generate import apply_repetition_penalty
+    g = torch.Generator().manual_seed(5)
+    for penalty in (1.0, 1.2, 2.5):
+        scores = torch.randn(257, generator=g) * 3
+        scores[7] = 0.0
+        generated = [3, 7, 7, 200, 3, 256, 0]
+        want = lp.RepetitionPenaltyLogitsProcessor(penalty=penalty)(torch.tensor([generated]), scores[None].clone())[0] \
+            if penalty != 1.0 else scores.clone()
+        got = apply_repetition_penalty(scores.clone(), generated, penalty)
+        assert torch.equal(got, want)
