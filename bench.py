@@ -254,6 +254,27 @@ def main():
             cpu_ms = (time.perf_counter() - t0) * 1e3
             result['preprocess_f1'] = {'workload': '788x2000 page -> 11 page tiles + 96 character tiles (bf16, normalised)', 'gpu_ms_per_page': round(gpu_ms, 3),
                                        'host_pil_ms_per_page': round(cpu_ms, 1), 'parity': 'bit-exact (tests/test_gpu_prep.py)'}
+            # the OrderFormer scorer of the ordering front end, 64 pages x 50 boxes per call
+            from callireader_amd import synthetic as syn
+            from oracle import orderformer as oracle_of
+            sd_of = syn.make_orderformer_state_dict(seed=11)
+            model.load_orderformer(sd_of)
+            xb = torch.rand(64, 50, 4, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+            xd = xb.to(dev)
+            eng.orderformer(xd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                eng.orderformer(xd)
+            torch.cuda.synchronize()
+            of_gpu_ms = (time.perf_counter() - t0) / 10 * 1e3
+            cpu_of = oracle_of.CpuScorer(sd_of)
+            t0 = time.perf_counter()
+            cpu_of.orderformer(xb[:8])
+            of_cpu_ms = (time.perf_counter() - t0) * 1e3 / 8
+            result['ordering_f4'] = {'workload': 'OrderFormer (4 layers, d 256, 8 heads) on 64 pages x 50 boxes, bf16',
+                                     'gpu_ms_per_page': round(of_gpu_ms / 64, 4), 'cpu_oracle_ms_per_page': round(of_cpu_ms, 2),
+                                     'parity': 'scores within 4 % of the oracle model, reading order = the reference on 5 pages (tests/test_gpu_ordering.py)'}
         if not args.no_cpu_baseline:
             del model
             result['cpu_baseline'] = cpu_baseline()

@@ -39,6 +39,7 @@ SIGNATURES = {
     'cr_preprocess': (i32, [vp, vp, i32, i32, vp, i32, vp, vp, i32, vp]),
     'cr_resample': (i32, [vp, vp, i32, vp, vp]),
     'cr_vq': (i32, [vp, vp, i32, vp, vp, vp]),
+    'cr_orderformer': (i32, [vp, vp, i32, i32, vp, vp]),
     'cr_denorm': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'cr_embed_splice': (i32, [vp, vp, i32, vp, i32, i64, vp, i32, i64, vp, vp]),
     'cr_kv_alloc': (i32, [vp, i32, i32, C.POINTER(vp)]),

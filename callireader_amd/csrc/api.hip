@@ -126,7 +126,7 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
     CR_HIP(hipMemcpyAsync(t.ptr, src, t.bytes, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (src_is_host) CR_HIP(hipStreamSynchronize((hipStream_t)stream));   // caller may free host memory right away
     c->w[name] = t;
-    c->finalized = false;
+    if (strncmp(name, "orderformer.", 12) != 0) c->finalized = false;      // the sorter (f4) has no derived tensors to refresh
     return CR_OK;
 }
 

@@ -132,6 +132,15 @@ class Engine:
         B.check(B.lib.cr_resample(self._h, _p(feats), T, _p(out), _stream()), 'cr_resample')
         return out
 
+    def orderformer(self, boxes):
+        """boxes (B, L, 4) bf16 -> (B, L) fp32 scores of the OrderFormer (weights `orderformer.*` loaded beforehand)."""
+        x = boxes.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        Bn, L, four = x.shape
+        assert four == 4
+        out = torch.empty(Bn, L, device=self.device, dtype=torch.float32)
+        B.check(B.lib.cr_orderformer(self._h, _p(x), Bn, L, _p(out), _stream()), 'cr_orderformer')
+        return out
+
     def vq(self, x, with_cos=False):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         n = x2.shape[0]

@@ -43,6 +43,7 @@ class InternVLChatModel:
         self.system_message = self.conv_template.system_message            # :194
         self.max_tokens = max_tokens
         self.max_pages = max_pages
+        self.sorter = None                 # ordering.OrderFormer once load_orderformer() has run (modeling_internvl_chat.py:159)
         self.gpu_preprocess = True       # tiles are cut/resized/normalised on the GPU (bit-identical to the PIL path)
         self._kv = None
         self._ready = False
@@ -74,6 +75,9 @@ class InternVLChatModel:
         m = cls(kw.pop('dims', None), **kw)
         load_checkpoint(m.engine, path, params_dir)
         m._finish()
+        of = os.path.join(params_dir, 'orderformer.pth')                    # :159 ORDERFORMER_CHECKPOINT
+        if os.path.exists(of):
+            m.load_orderformer(torch.load(of, map_location='cpu', weights_only=True))
         return m
 
     def _finish(self):
@@ -123,15 +127,25 @@ class InternVLChatModel:
 
     def calli_align(self, img_path, detect_model, drop_zero=False, use_hard_vector_quant=False, save_path=None,
                     verbose=False, boxes=None):
-        """:322-640.  Boxes come from `boxes=` or from `detect_model(img)` (ordered xyxy, pixels)."""
+        """:322-640.  Boxes come from `boxes=` (reading order), or from `detect_model`:
+          * with a sorter loaded (`load_orderformer`): `detect_model(image array)` returns RAW detections in any order
+            and the reference's front end runs on them -- repeated detection passes, duplicate removal, column merge /
+            area split, OrderFormer, per-column top-to-bottom (ordering.py, :346-556);
+          * without one: `detect_model(PIL image)` must return the boxes already in reading order.
+        The detector network itself (YOLOv10 through ultralytics) is third-party and stays outside this package."""
         if img_path is None:
             return None, None                                               # :554-555
         img = Image.open(img_path).convert('RGB') if isinstance(img_path, str) else img_path.convert('RGB')
         if boxes is None:
             if not callable(detect_model):
-                raise NotImplementedError('the YOLO + OrderFormer front end is outside this engine (SURVEY.md 8f-4): '
-                                          'pass boxes=[(x1,y1,x2,y2),...] or a callable detect_model(img)')
-            boxes = detect_model(img)
+                raise NotImplementedError('the detector network is outside this engine (SURVEY.md 8f-4): pass '
+                                          'boxes=[(x1,y1,x2,y2),...] or a callable detect_model')
+            if self.sorter is not None:
+                from . import ordering
+                raw = ordering.detect_all(detect_model, np.array(img))
+                boxes = ordering.sort_boxes(raw, img.width, img.height, self.sorter)      # :558
+            else:
+                boxes = detect_model(img)
         arr = np.array(img)
         if self.gpu_preprocess:
             # one page upload, every crop resized/padded/normalised by cr_preprocess (replaces the per-box PIL loop :580-583)
@@ -149,6 +163,12 @@ class InternVLChatModel:
                 tiles.append(load_image_2(Image.fromarray(arr[y1:y2, x1:x2])).to(torch.bfloat16))
             results = torch.cat(tiles).to(self.device)                      # :585
         return self.align_tiles(results, drop_zero, use_hard_vector_quant, verbose)
+
+    def load_orderformer(self, state_dict, max_nums=50):
+        """:159, models/model.py:530-552: `state_dict` = params/orderformer.pth (the reference's `Transformer` keys)."""
+        from .ordering import OrderFormer
+        self.sorter = OrderFormer.from_state_dict(self.engine, state_dict, max_nums=max_nums)
+        return self.sorter
 
     # ---- generation ----------------------------------------------------------------------------
     def _greedy(self, input_embeds, max_new_tokens, eos_token_id, repetition_penalty, check_every=16):

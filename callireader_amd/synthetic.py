@@ -165,3 +165,36 @@ def iter_state_dict(dims: ModelDims, parts=('vit', 'mlp1', 'resampler', 'vq', 'l
 def make_pixels(n_tiles, seed=0, device='cpu', dtype=torch.bfloat16, size=448):
     """ImageNet-normalised pixels are ~N(0,1)."""
     return _randn('pixel_values', (n_tiles, 3, size, size), 1.0, seed, device, dtype)
+
+
+# ---- OrderFormer (params/orderformer.pth, models/model.py:206-233,530-552) --------------------------------------
+ORDERFORMER = dict(max_nums=50, input_dim=4, model_dim=256, num_heads=8, num_layers=4, ff=2048)
+
+
+def orderformer_keys(cfg=ORDERFORMER):
+    """state_dict keys of the reference's `Transformer` (nn.Linear embedding, nn.TransformerEncoder of post-norm
+    nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward=2048, relu), nn.Linear decoder, no final norm).
+    The template layer `encoder_layer.*` is a registered sub-module too, so a strict load needs it although only
+    its deep copies `transformer_encoder.layers.N.*` run."""
+    d, ff = cfg['model_dim'], cfg['ff']
+    specs = {'embedding.weight': ((d, cfg['input_dim']), 0.7, 0.0), 'embedding.bias': ((d,), 0.1, 0.0),
+             'decoder.weight': ((1, d), 0.08, 0.0), 'decoder.bias': ((1,), 0.1, 0.0)}
+    prefixes = ['encoder_layer.'] + [f'transformer_encoder.layers.{i}.' for i in range(cfg['num_layers'])]
+    for p in prefixes:
+        specs[p + 'self_attn.in_proj_weight'] = ((3 * d, d), d ** -0.5, 0.0)
+        specs[p + 'self_attn.in_proj_bias'] = ((3 * d,), 0.05, 0.0)
+        specs[p + 'self_attn.out_proj.weight'] = ((d, d), d ** -0.5, 0.0)
+        specs[p + 'self_attn.out_proj.bias'] = ((d,), 0.05, 0.0)
+        specs[p + 'linear1.weight'] = ((ff, d), d ** -0.5, 0.0)
+        specs[p + 'linear1.bias'] = ((ff,), 0.05, 0.0)
+        specs[p + 'linear2.weight'] = ((d, ff), ff ** -0.5, 0.0)
+        specs[p + 'linear2.bias'] = ((d,), 0.05, 0.0)
+        for n in ('norm1', 'norm2'):
+            specs[p + n + '.weight'] = ((d,), 0.1, 1.0)
+            specs[p + n + '.bias'] = ((d,), 0.05, 0.0)
+    return specs
+
+
+def make_orderformer_state_dict(seed=0, device='cpu', dtype=torch.bfloat16, cfg=ORDERFORMER):
+    return {k: _randn('orderformer.' + k, shape, std, seed, device, dtype, mean=mean)
+            for k, (shape, std, mean) in orderformer_keys(cfg).items()}

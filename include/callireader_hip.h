@@ -144,6 +144,13 @@ int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int6
 int cr_profile(cr_ctx* ctx, int enable);
 int cr_profile_read(cr_ctx* ctx, double* out8);
 
+/* ---- ordering front end ------------------------------------------------------------- */
+/* OrderFormer.model forward -- models/model.py:206-233, called from predict :458-461.
+ * boxes [B][L][4] bf16 (L <= 64; the reference pads every page to max_nums = 50 rows) -> scores [B][L] fp32
+ * (= the bf16 decoder output).  Weights: the reference's `Transformer` state_dict keys under "orderformer."
+ * (embedding.*, transformer_encoder.layers.N.*, decoder.*), loaded with cr_load_weight. */
+int cr_orderformer(cr_ctx* ctx, const void* boxes, int B, int L, float* scores, void* stream);
+
 /* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
 /* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32.
  * Bits 8..15 of epi pin a kernel for the unit tests: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent,
