@@ -39,6 +39,9 @@ __device__ __forceinline__ float hi_bf16(unsigned pk) { return __uint_as_float(p
 template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
 template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
 
+// Measured nulls at the ViT shape (0.55 ms either way; PMC: waves issue 27 % of their cycles, sit in issue stalls 40 %,
+// parked 33 %): three K/V stages with a counted wait instead of two drained ones (-5 %: one workgroup fewer per CU),
+// a 128-VGPR budget for four workgroups per CU (+-0), packed fp32 math for the exponent arguments and row sums (+-0).
 template <int D, bool CAUSAL, bool SPLIT = false, bool DIV = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,17 +205,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         const float m2 = m_new * LOG2E;                       // exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp_f32
         const float alpha = rescale ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
         m_run = m_new;
-        float psum = 0.f;
+        // exponentials on pairs: packed fp32 math (v_pk_fma_f32 / v_pk_add_f32) halves the FMA and row-sum issue slots
+        f32x2_t psum2 = {0.f, 0.f};
+        const f32x2_t l2e = {LOG2E, LOG2E}, negm = {-m2, -m2};
         unsigned ppk[2][8];                                   // P as packed bf16 pairs: the PV B-operand, 4 dwords per fragment
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(lo_bf16(spk[kb][i]), LOG2E, -m2));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(hi_bf16(spk[kb][i]), LOG2E, -m2));
-                psum += p0 + p1;
-                ppk[kb][i] = pack_bf16(p0, p1);
+                const f32x2_t sv = {lo_bf16(spk[kb][i]), hi_bf16(spk[kb][i])};
+                const f32x2_t arg = __builtin_elementwise_fma(sv, l2e, negm);
+                const f32x2_t pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                psum2 += pv;
+                ppk[kb][i] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2));
             }
+        const float psum = psum2[0] + psum2[1];
         l_run = l_run * alpha + psum;
         if (rescale) {
 #pragma unroll
