@@ -145,7 +145,7 @@ int launch_w(const GemmParams& p, hipStream_t stream) {
     if (p.N <= 8192 && p.K % 256 == 0) return launch_mt<EPI, 8, 1>(p, stream);
     // four row tiles per wave where N still fills the chip: a quarter of the X re-reads (w1|w3 at M = 32: 81 us with
     // two tiles, 63 us with four, 71 us with eight -- eight leaves 224 workgroups for 256 CUs)
-    if (p.N >= 16384 && p.M > 16) return launch_mt<EPI, 4, 4>(p, stream);
+    if (p.N >= 16384 && p.M > 8) return launch_mt<EPI, 4, 4>(p, stream);        // M = 16: 62.8 -> 55.7 us; M <= 8: +-0
     return launch_mt<EPI, 4, 1>(p, stream);
 }
 
