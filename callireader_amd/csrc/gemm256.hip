@@ -416,11 +416,12 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 bool gemm256_supported(int epi, const GemmParams& p) {
     if (p.M < 2048 || p.N < 512 || (p.K % 128) != 0) return false;
     // wave-quantisation model (calibrated on the measured shapes): a round of 256x256 tiles on
-    // 256 CUs costs 1, a round of 512 co-resident 128x128 tiles 0.55; pick the kernel with the cheaper schedule
+    // 256 CUs costs 1; a round of 512 co-resident 128x128 tiles covers half the output at ~0.65 of this kernel's rate
+    // (ViT shapes: 0.50-0.82 vs 0.78-1.23 PFLOP/s), i.e. 0.75; pick the kernel with the cheaper schedule
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const double c256 = (double)((t256 + 255) / 256);
-    const double c128 = 0.55 * (double)((t128 + 511) / 512);
+    const double c128 = 0.75 * (double)((t128 + 511) / 512);
     return c256 <= c128;
 }
 

@@ -222,6 +222,30 @@ def test_gemm_patch_rows(E, kern):
     assert torch.equal(got[:, 0], torch.zeros(T, N, device=dev()))      # CLS rows are not this kernel's
 
 
+@pytest.mark.parametrize('epi', [0, 3, 6])
+def test_gemm256_ragged_n(E, epi):
+    """256x256 kernel on an N that is no multiple of 4 (the vocabulary is 92 553): the last column block takes the
+    element-wise epilogue, bias / residual / fp32 output included."""
+    g = torch.Generator().manual_seed(40 + epi)
+    M, N, K = 2100, 1003, 128
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.05)).to(dev())
+    bias = bf(_rand((N,), g, 0.1)).to(dev())
+    res = bf(_rand((M, N), g)).to(dev())
+    lin = rb(A.float() @ W.float().t() + bias.float())
+    if epi == 6:
+        out = E.op_gemm(6, A, W, bias=bias, out_dtype=torch.float32, kernel=2)
+        ref = lin
+    elif epi == 3:
+        out = E.op_gemm(3, A, W, bias=bias, res=res, kernel=2).float()
+        ref = rb(res.float() + lin)
+    else:
+        out = E.op_gemm(0, A, W, bias=bias, kernel=2).float()
+        ref = lin
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=RTOL, atol=2e-2)
+
+
 def test_gemm_ragged_n_and_f32(E):
     g = torch.Generator().manual_seed(4)
     M, N, K = 70, 1003, 128           # N not a multiple of 8 (like vocab 92553)
