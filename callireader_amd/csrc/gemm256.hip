@@ -57,8 +57,9 @@
 // (vmcnt(0)) before the epilogue, which lets slots 1..4 of the next tile skip their counted wait: on the in-order
 // counter that wait would otherwise sit behind the tile's output stores.
 // In-kernel stamps (-DCR_DIAG_STAMPS, s_memtime into the buffer passed as `scale`): K = 1024 tiles spend 39.1 k
-// clocks in the main loop, 0.4 k draining the look-ahead and 6.0 k in the epilogue; the sustained clock under this
-// load is ~1.3 GHz, which is what keeps the absolute rate under half the 2.4 GHz peak.
+// clocks in the main loop, 0.4 k draining the look-ahead and 6.0 k in the epilogue.  The clock the chip sustains under
+// this kernel, measured as d(s_memtime) / d(s_memrealtime) x 100 MHz after 200 back-to-back launches, is 1.82-1.92 GHz
+// (K = 8192 lowest), so the matrix peak actually on offer is ~1.9-2.0 PFLOP/s, not the 2.5 of the 2.4 GHz figure.
 #include <stdlib.h>
 
 #include "gemm_epilogue.hpp"
