@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         // a wave whose 32 query rows are all padding (ragged last query block; decode's 4-row blocks) only helps
         // staging (wave-uniform branch)
         if (qb * 128 + wave * 32 < p.Sq) {
-        const bool two_blocks = Sk - kt * 64 > 32;       // ragged last key tile: skip its empty 32-key half
+        // (a ragged last key tile runs both 32-key halves: the empty one is masked to -inf anyway, and skipping it
+        //  cost every tile 16 accumulator-zeroing moves plus two branches on an issue-bound loop)
 
         // ---- S^T = K . Q^T for two 32-key blocks ----
         f32x16 sacc[2];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) sacc[kb][e] = 0.f;
-            if (kb == 0 || two_blocks) {
+            {
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     const bf16x8 kf = *(const bf16x8*)(kbuf + kb * 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
                         s0 = (key < Sk && (!CAUSAL || key <= qpos)) ? s0 : -INFINITY;
                         s1 = (key + 1 < Sk && (!CAUSAL || key + 1 <= qpos)) ? s1 : -INFINITY;
                     }
-                    mraw = fmaxf(mraw, fmaxf(s0, s1));
+                    mraw = fmaxf(fmaxf(mraw, s0), s1);          // one v_max3_f32 per pair
                     unsigned pk = pack_bf16(s0, s1);
                     if (DIV) pk = pack_bf16(lo_bf16(pk) * inv_div, hi_bf16(pk) * inv_div);
                     spk[kb][e >> 1] = pk;
@@ -231,7 +232,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            if (kb == 1 && !two_blocks) break;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
