@@ -41,7 +41,11 @@ template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (
 
 // Measured nulls at the ViT shape (0.55 ms either way; PMC: waves issue 27 % of their cycles, sit in issue stalls 40 %,
 // parked 33 %): three K/V stages with a counted wait instead of two drained ones (-5 %: one workgroup fewer per CU),
-// a 128-VGPR budget for four workgroups per CU (+-0), packed fp32 math for the exponent arguments and row sums (+-0).
+// a 128-VGPR budget for four workgroups per CU (+-0), packed fp32 math for the exponent arguments and row sums (+-0),
+// 256-row workgroups of 8 waves sharing each K/V tile (half the L2 -> LDS traffic, +-0), s_setprio 1 around the MFMA
+// clusters (-3 %), V fragments read ahead of the softmax (-15 %: the 32 registers cost a resident workgroup).  What the
+// counters add up to instead: per wave and 64-key tile ~945 cycles of vector issue + 512 of MFMA + ~200 of LDS/scalar
+// issue = the ~1690 cycles observed -- on this mix the SIMD's matrix and vector work do not overlap.
 template <int D, bool CAUSAL, bool SPLIT = false, bool DIV = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
