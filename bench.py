@@ -142,17 +142,22 @@ def main():
     char_px = synthetic.make_pixels(ct_hi - ct_lo, seed=20 + rank, device=dev)
     ids = [build_ids(PAGE_TILES, CHAR_TILES, TEXT_TOKENS, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, 1000 + p).to(dev) for p in mine]
 
-    def step():
+    def step(new_tokens=None, stamps=None):
+        new_tokens = NEW_TOKENS if new_tokens is None else new_tokens
         vit_mine = model.extract_feature(page_px)                                    # (my pages * 11, 256, 4096), stays local
         pseudo_local, _ = model.align_tiles(char_px)                                 # (3 * my char-tile shard, 4096)
+        if stamps is not None:
+            torch.cuda.synchronize(); stamps.append(time.perf_counter())
         pseudo_all = all_gather_rows(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile
         embeds = []
         for j, p in enumerate(mine):
             v = vit_mine[j * PAGE_TILES:(j + 1) * PAGE_TILES]
             r = pseudo_all[p * CHAR_TILES:(p + 1) * CHAR_TILES]
             embeds.append(eng.embed_splice(ids[j], v, r, img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID))
-        outs = model.generate_pages(embeds, max_new_tokens=NEW_TOKENS, eos_token_id=None)
-        assert all(len(o) == NEW_TOKENS for o in outs)
+        outs = model.generate_pages(embeds, max_new_tokens=new_tokens, eos_token_id=None)
+        assert all(len(o) == new_tokens for o in outs)
+        if stamps is not None:
+            torch.cuda.synchronize(); stamps.append(time.perf_counter())
         return outs
 
     def sync():
@@ -178,6 +183,19 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # north_star's "MFMA utilisation on ViT + LLM prefill": one extra, untimed pass that stops after the first token
+    # (visual stage, then splice + prefill + the first LM-head row), algorithmic FLOPs of SURVEY 8(d) over its wall time
+    st = [0.0]
+    torch.cuda.synchronize(); st[0] = time.perf_counter()
+    step(new_tokens=1, stamps=st)
+    my_tiles = len(mine) * PAGE_TILES + (ct_hi - ct_lo)
+    vis_fl = my_tiles * (723.6e9 + 17.18e9) + (ct_hi - ct_lo) * (12.02e9 + 2.27e9)
+    pre_fl = len(mine) * (S_page * 13.96e9 + 0.524e6 * S_page * (S_page + 1) / 2 + 0.758e9)
+    vit_prefill = {'what': 'visual stage (ViT + mlp1 + resampler + VQ) and LLM prefill of one batch, attention and norms included; algorithmic FLOPs of SURVEY 8(d) / wall time of an untimed extra pass on rank 0',
+                   'visual_ms': round((st[1] - st[0]) * 1e3, 1), 'prefill_ms': round((st[2] - st[1]) * 1e3, 1),
+                   'tflops': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12, 1),
+                   'mfma_frac': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     result = None
     if rank == 0:
@@ -207,6 +225,7 @@ def main():
                          'launches': int(big_n), 'avg_launch_ms': round(big_ms / max(big_n, 1), 4),
                          'flops_per_launch': round(big_fl / max(big_n, 1), 1),
                          'how': 'HIP events around every launch on the launch stream during the timed steps (cr_profile)'},
+            'vit_prefill': vit_prefill,
             'decode_gemm': {'bound': 'hbm', 'kernel': 'gemm_skinny_kernel (weight streaming, M <= 64: batched decode, LM head) and tiled launches with M < 1024 (resampler rows)',
                             'achieved': round(sm_by / (sm_ms * 1e-3) / 1e9, 1) if sm_ms > 0 else 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                             'frac': round(sm_by / (sm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sm_ms > 0 else 0.0,
