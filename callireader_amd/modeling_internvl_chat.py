@@ -355,7 +355,7 @@ class InternVLChatModel:
 
     # ---- page-parallel generation (new: the reference decodes one page at a time) ---------------
     def generate_pages(self, embeds_list, max_new_tokens=1024, eos_token_id=EOS_TOKEN_ID, repetition_penalty=1.0,
-                       check_every=16, prefill_batch=8):
+                       check_every=16, prefill_batch=16):
         """Prefill every page, then decode all unfinished pages as ONE batch per step: the 14.7 GB of LLM weights are
         streamed once per step for all pages.  Per page the ids equal the single-page greedy result."""
         P = len(embeds_list)
