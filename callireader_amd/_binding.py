@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ModelDesc(C.Structure):

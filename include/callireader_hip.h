@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 1
+#define CR_ABI_VERSION 2   /* 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7) */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3 };
@@ -152,7 +152,8 @@ int cr_profile_read(cr_ctx* ctx, double* out8);
 int cr_orderformer(cr_ctx* ctx, const void* boxes, int B, int L, float* scores, void* stream);
 
 /* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
-/* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32.
+/* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32,
+ * 7 decode partial sums (M <= 64, no bias: C = fp32 [S][M][N], S <= 8 K-slices summed by the consumer).
  * Bits 8..15 of epi pin a kernel for the unit tests: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent,
  * 3 weight-streaming (M <= 64); a pinned kernel that cannot take the shape returns CR_ERR_ARG. */
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
