@@ -152,7 +152,7 @@ int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (force == 256) return (p.K % 128) == 0 ? launch_gemm256(epi, p, stream) : CR_ERR_ARG;
     if (force != 128) {
         if (gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
-        if (gemm256_supported(epi, p)) return launch_gemm256(epi, p, stream);           // large M: 256x256 8-phase kernel
+        if (gemm256_supported(epi, p)) return launch_gemm256(epi, p, stream);           // large M: persistent 256x256 kernel
     }
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE>(p, stream);
