@@ -123,7 +123,7 @@ def main():
     from callireader_amd.config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID
     from callireader_amd import synthetic, _binding as B
     from callireader_amd.modeling_internvl_chat import InternVLChatModel
-    from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages
+    from callireader_amd.parallel import shard_range, all_gather_rows_async, owned_pages
 
     dims = ModelDims.full()
     P = args.pages
@@ -144,11 +144,12 @@ def main():
 
     def step(new_tokens=None, stamps=None):
         new_tokens = NEW_TOKENS if new_tokens is None else new_tokens
-        vit_mine = model.extract_feature(page_px)                                    # (my pages * 11, 256, 4096), stays local
         pseudo_local, _ = model.align_tiles(char_px)                                 # (3 * my char-tile shard, 4096)
+        gathered = all_gather_rows_async(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile, over xGMI ...
+        vit_mine = model.extract_feature(page_px)                                    # ... underneath the owner's page tiles (my pages * 11, 256, 4096)
         if stamps is not None:
             torch.cuda.synchronize(); stamps.append(time.perf_counter())
-        pseudo_all = all_gather_rows(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile
+        pseudo_all = gathered()
         embeds = []
         for j, p in enumerate(mine):
             v = vit_mine[j * PAGE_TILES:(j + 1) * PAGE_TILES]

@@ -52,5 +52,32 @@ def all_gather_rows(local, total, group=None):
     return torch.cat([recv[r * mx:r * mx + c] for r, c in enumerate(counts)], dim=0)
 
 
+def all_gather_rows_async(local, total, group=None):
+    """Start the gather and return `finish() -> (total, ...) tensor`: on RCCL the collective runs on the communicator's
+    own stream, so kernels enqueued before finish() (the page tiles' ViT, in bench.py) overlap the transfer over xGMI.
+    World size 1 and the gloo host fallback complete immediately."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 or (local.is_cuda and dist.get_backend(group) == 'gloo'):
+        out = all_gather_rows(local, total, group)
+        return lambda: out
+    counts = shard_counts(total, world)
+    assert local.shape[0] == counts[dist.get_rank(group)], (local.shape, counts)
+    mx = max(counts)
+    tail = local.shape[1:]
+    send = local
+    if local.shape[0] != mx:
+        send = torch.zeros((mx,) + tuple(tail), dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
+    recv = torch.empty((world * mx,) + tuple(tail), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(recv, send.contiguous(), group=group, async_op=True)
+
+    def finish():
+        work.wait()                                   # the current stream waits for the collective; the host does not block
+        if all(c == mx for c in counts):
+            return recv
+        return torch.cat([recv[r * mx:r * mx + c] for r, c in enumerate(counts)], dim=0)
+    return finish
+
+
 def owned_pages(n_pages, world, rank):
     return list(range(rank, n_pages, world))

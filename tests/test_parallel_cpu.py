@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from callireader_amd.parallel import shard_range, shard_counts, all_gather_rows, owned_pages
+from callireader_amd.parallel import shard_range, shard_counts, all_gather_rows, all_gather_rows_async, owned_pages
 
 
 def test_shard_range_is_an_even_contiguous_partition():
@@ -42,6 +42,9 @@ def _worker(rank, world, port, total, q):
         # an int64 tensor (VQ indices) rides the same path
         idx = torch.arange(total, dtype=torch.int64).reshape(total, 1)
         ok = ok and torch.equal(all_gather_rows(idx[lo:hi].clone(), total), idx)
+        # the overlapped form bench.py uses: start, do other work, finish
+        finish = all_gather_rows_async(full[lo:hi].clone(), total)
+        ok = ok and torch.equal(finish(), full)
         q.put((rank, bool(ok), tuple(got.shape)))
     finally:
         dist.destroy_process_group()
