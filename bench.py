@@ -249,6 +249,19 @@ def main():
                                      'ms': round(dt * 1e3, 2), 'tflops': round(32 * 723.6e9 / dt / 1e12, 1),
                                      'mfma_frac': round(32 * 723.6e9 / dt / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if not args.no_vit_extra:
+            # BASELINE config 3: one image through the whole path on one GPU (latency view: batch of one page)
+            one_page, one_char = page_px[:PAGE_TILES], char_px[:CHAR_TILES]
+
+            def single():
+                v = model.extract_feature(one_page)
+                r, _ = model.align_tiles(one_char)
+                e = eng.embed_splice(ids[0], v, r.reshape(-1, 3, dims.llm_hidden), img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID)
+                return model.generate_pages([e], max_new_tokens=NEW_TOKENS, eos_token_id=None)
+            single(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            single(); torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            result['config3_single_image'] = {'workload': 'one page (107 tiles, 3164-token prompt, 128 greedy tokens), batch of one', 's_per_page': round(dt1, 4)}
             # tile preprocessing of one example-shaped page (788x2000, 11 page tiles + 96 character crops)
             import numpy as np
             from PIL import Image
