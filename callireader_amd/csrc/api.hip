@@ -51,7 +51,7 @@ int ws_ensure(cr_ctx* c, size_t bytes) {
 
 int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
     cr_ctx::ProfRec rec{};
-    const bool on = c->prof && c->prof_recs.size() < 200000;
+    const bool on = c->prof && (c->prof_mode != 2 || p.M >= 1024) && c->prof_recs.size() < 200000;
     if (on) {
         for (hipEvent_t* e : {&rec.a, &rec.b}) {
             if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
@@ -86,6 +86,7 @@ int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     c->device = device;
     c->d = *desc;
     { const char* e = getenv("CR_NO_SLICED_DECODE"); c->no_sliced_decode = e && atoi(e) != 0; }
+    { const char* e = getenv("CR_DECODE_GRAPH"); if (e) c->decode_graph = atoi(e) != 0; }
     c->scratch_bytes = 1 << 20;
     if (hipMalloc((void**)&c->scratch, c->scratch_bytes) != hipSuccess) { delete c; return cr_fail(CR_ERR_NOMEM, "scratch"); }
     hipMemset(c->scratch, 0, c->scratch_bytes);
@@ -100,6 +101,7 @@ int cr_destroy(cr_ctx* c) {
     for (auto& kv : c->w) if (kv.second.ptr) hipFree(kv.second.ptr);
     if (c->ws) hipFree(c->ws);
     if (c->scratch) hipFree(c->scratch);
+    if (c->side) hipStreamDestroy(c->side);
     for (auto& r : c->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) hipEventDestroy(e);
     delete c;
@@ -126,6 +128,7 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
     CR_HIP(hipMemcpyAsync(t.ptr, src, t.bytes, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (src_is_host) CR_HIP(hipStreamSynchronize((hipStream_t)stream));   // caller may free host memory right away
     c->w[name] = t;
+    c->weight_gen++;
     if (strncmp(name, "orderformer.", 12) != 0) c->finalized = false;      // the sorter (f4) has no derived tensors to refresh
     return CR_OK;
 }
@@ -133,6 +136,7 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
 int cr_profile(cr_ctx* c, int enable) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_profile: null context");
     c->prof = enable != 0;
+    c->prof_mode = enable;
     return CR_OK;
 }
 

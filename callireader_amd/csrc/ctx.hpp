@@ -20,6 +20,11 @@ struct cr_ctx {
     int device = 0;
     cr_model_desc d{};
     bool finalized = false;
+    int prof_mode = 0;                  // cr_profile: 1 = every GEMM launch, 2 = only the tiled class (M >= 1024): leaves decode free to run as a graph
+    int decode_graph = 0;               // CR_DECODE_GRAPH=1 replays the decode step as a captured hipGraph (measured slower here, see llm.hip); reset to 0 after a capture failure
+    hipStream_t side = nullptr;         // blocking stream the decode graph is captured into and replayed on when the caller's stream is the
+                                        // null stream (which cannot be captured); implicitly ordered with it
+    uint64_t weight_gen = 0;            // bumped by cr_load_weight / cr_finalize: captured graphs hold weight pointers
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
     std::unordered_map<std::string, DevTensor> w;
     // workspace

@@ -141,6 +141,8 @@ int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int6
  * HIP events on the launch stream.  cr_profile_read synchronises and returns, for the compute-bound class
  * (M >= 1024 rows) in out[0..3] = {launches, summed kernel ms, summed algorithmic FLOPs (2*M*N*K), algorithmic bytes} and for the
  * weight-streaming class (M < 1024) in out[4..7] = {launches, ms, FLOPs, algorithmic bytes (W + A + C)}; then clears. */
+/* enable: 0 off, 1 every GEMM launch, 2 only the compute-bound class (batched decode then runs as a captured hipGraph,
+ * whose launches cannot carry events). */
 int cr_profile(cr_ctx* ctx, int enable);
 int cr_profile_read(cr_ctx* ctx, double* out8);
 
