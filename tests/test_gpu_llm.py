@@ -136,6 +136,35 @@ def test_batched_decode_equals_single(setup):
     kv.free()
 
 
+def test_decode_graph_replay_equals_plain_launches(setup):
+    """CR_DECODE_GRAPH=1 (opt-in): the decode step captured as a hipGraph and replayed -- across a change of the number
+    of attention splits (a second capture) and with prefills in between -- generates exactly the plain path's ids."""
+    import os
+    from callireader_amd.engine import Engine
+    embs = [prompt(250, 41), prompt(120, 42), prompt(33, 43)]
+
+    def run(eng):
+        kv = eng.kv_alloc(3, 512)
+        for i, e in enumerate(embs):
+            eng.prefill(kv, i, e.cuda())
+        for _ in range(12):                          # sequence 0 crosses 256 cached tokens: the split count grows
+            eng.decode(kv, [0, 1, 2])
+        out = [kv.generated(i) for i in range(3)]
+        kv.free()
+        return out
+    plain = run(setup['eng'])
+    os.environ['CR_DECODE_GRAPH'] = '1'
+    try:
+        eng2 = Engine(setup['dims'], max_pos=2048)
+    finally:
+        del os.environ['CR_DECODE_GRAPH']
+    eng2.load_state_dict(setup['sd'])
+    eng2.load_rope()
+    eng2.finalize()
+    assert run(eng2) == plain
+    assert run(eng2) == plain                        # replays of the cached graphs on a fresh cache
+
+
 def test_prefill_batch_equals_single(setup):
     """Prompts of several pages share the linear layers' GEMMs; each page must get exactly its own single-prefill result
     (the tiled GEMM kernels accumulate K in the same order for every row, attention stays per page)."""
