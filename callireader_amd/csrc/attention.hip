@@ -61,8 +61,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int qb = SPLIT ? 0 : blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
-    const int split = SPLIT ? blockIdx.x : 0;
+    // XCD-aware order: workgroups b and b + 8 share an XCD (and its L2), so the linear id is remapped bijectively to
+    // give every XCD a contiguous run of the (batch, head, x) space: the query blocks (or key splits) of one (batch, head)
+    // read their K/V through ONE L2 instead of up to eight
+    int bx, head, batch;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int total = gx * gy * (int)gridDim.z;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * (int)blockIdx.z);
+        const int xcd = lin & 7, q = total >> 3, r = total & 7;
+        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        bx = pid % gx;
+        head = (pid / gx) % gy;
+        batch = pid / (gx * gy);
+    }
+    const int qb = SPLIT ? 0 : bx;
+    const int split = SPLIT ? bx : 0;
     const int kvh = head / p.kv_group;
     const int slot = p.seq_map ? p.seq_map[batch] : batch;
     const int Sk = p.sk_arr ? p.sk_arr[slot] + p.sk_add : p.Sk;
