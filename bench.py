@@ -25,6 +25,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL; must be set before HIP initialises
 
+
+
+def _self_launch(argv):
+    """`python bench.py --gpus N` run directly (no torch.distributed.run around it): start N ranks ourselves.  This
+    process has not touched HIP yet (only the standard library is imported above), so it can spawn children freely; it
+    never replaces itself by exec, it waits for the launcher and leaves with its exit code."""
+    import socket
+    import subprocess
+    n = 1
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith('--gpus='):
+            n = int(a.split('=', 1)[1])
+    if n <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.call(cmd))
+
+
+if __name__ == '__main__':
+    _self_launch(sys.argv[1:])
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -107,10 +135,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    backend = os.environ.get('CR_DIST_BACKEND', 'nccl')      # 'gloo' lets several ranks share one GPU on a test box
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus N` (it starts the N ranks itself) '
+                         'or launch N ranks with torch.distributed.run')
+    backend = os.environ.get('CR_DIST_BACKEND', 'nccl') if world > 1 else 'none'     # 'gloo' lets several ranks share one GPU on a test box
+    n_dev = torch.cuda.device_count()                            # counting devices does not initialise HIP
+    if n_dev < 1:
+        raise SystemExit('bench.py needs a GPU: there is no CPU fallback for the hot path')
+    if backend == 'nccl' and world > n_dev:
+        raise SystemExit(f'{world} ranks but {n_dev} visible GPU(s): RCCL needs one GPU per rank (CR_DIST_BACKEND=gloo shares a GPU on a test box)')
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -119,6 +153,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
 
     from callireader_amd.config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID
     from callireader_amd import synthetic, _binding as B
@@ -180,10 +215,32 @@ def main():
     import ctypes as C
     prof = (C.c_double * 8)()
     B.check(B.lib.cr_profile_read(eng._h, prof))
+    pstat = (C.c_int64 * 4)()
+    B.check(B.lib.cr_profile_stats(eng._h, pstat))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # the path's one collective, alone on the wire (untimed extra): the pseudo-token all-gather of one step
+    gather = None
+    if world > 1:
+        rows = torch.zeros(ct_hi - ct_lo, 3, dims.llm_hidden, device=dev, dtype=torch.bfloat16)
+        all_gather_rows_async(rows, n_pages * CHAR_TILES)()
+        sync()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            all_gather_rows_async(rows, n_pages * CHAR_TILES)()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        sync()
+        ms = sorted(ts)[2] * 1e3
+        total_bytes = n_pages * CHAR_TILES * 3 * dims.llm_hidden * 2
+        gather = {'collective': 'all_gather_into_tensor (pseudo-token embeddings of the character tiles)', 'backend': dist.get_backend(),
+                  'bytes_per_rank_sent': (ct_hi - ct_lo) * 3 * dims.llm_hidden * 2, 'bytes_gathered': total_bytes,
+                  'standalone_ms': round(ms, 3), 'gb_per_s_received': round(total_bytes * (world - 1) / world / (ms * 1e-3) / 1e9, 1),
+                  'note': 'inside a step the gather runs underneath the page tiles\' ViT (all_gather_rows_async)'}
 
     # north_star's "MFMA utilisation on ViT + LLM prefill": one extra, untimed pass that stops after the first token
     # (visual stage, then splice + prefill + the first LM-head row), algorithmic FLOPs of SURVEY 8(d) over its wall time
@@ -203,15 +260,18 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_pages / (elapsed / args.steps)
         big_n, big_ms, big_fl, big_by = prof[0], prof[1], prof[2], prof[3]
-        traffic = None
-        tp = os.path.join(ROOT, 'profiles', 'round1', 'traffic_pmc.json')
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get('gemm_tiled_big', {}).get('traffic_bytes_per_launch')
+        traffic, traffic_src = None, None
+        for rd in ('round2', 'round1'):
+            tp = os.path.join(ROOT, 'profiles', rd, 'traffic_pmc.json')
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get('gemm_tiled_big', {}).get('traffic_bytes_per_launch')
+                traffic_src = f'profiles/{rd}/traffic_pmc.json'
+                break
         sm_n, sm_ms, sm_fl, sm_by = prof[4], prof[5], prof[6], prof[7]
         achieved = big_fl / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
         result = {
             'metric': 'calligraphy pages/sec (ViT+resampler+LLM greedy)', 'value': round(value, 4), 'unit': 'pages/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
+            'n_gpus': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'full page path, {P} pages/GPU/step of the examples/0.jpg shape (11 page + 96 char tiles 448x448, '
                                    f'{S_page}-token prompt, {NEW_TOKENS} greedy tokens, repetition_penalty 1.0); InternVL2-8B shapes '
@@ -221,7 +281,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'tiled bf16 MFMA GEMM (gemm256_kernel, persistent 256x256, slot-staggered wave groups; gemm128_kernel where it schedules better), launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill',
                          'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_note': 'bytes per launch on the L2 fabric side (Infinity-Cache hits included), (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this bench at 8 pages x 4 new tokens: profiles/round1/traffic_pmc.json',
+                         'traffic_note': 'bytes per launch on the L2 fabric side (Infinity-Cache hits included), (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this bench: ' + str(traffic_src),
                          'algorithmic_bytes_per_launch': round(big_by / max(big_n, 1), 1),
                          'launches': int(big_n), 'avg_launch_ms': round(big_ms / max(big_n, 1), 4),
                          'flops_per_launch': round(big_fl / max(big_n, 1), 1),
@@ -232,6 +292,9 @@ def main():
                             'frac': round(sm_by / (sm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sm_ms > 0 else 0.0,
                             'launches': int(sm_n), 'kernel_ms_per_step': round(sm_ms / args.steps, 2)},
             'gemm_big_ms_per_step': round(big_ms / args.steps, 2),
+            'prof_truncated': bool(pstat[2] != 0 or pstat[0] != pstat[1] or int(big_n + sm_n) != pstat[0]),
+            'prof': {'launches_bracketed': int(pstat[0]), 'accounted': int(pstat[1]), 'lost': int(pstat[2]), 'peak_pending': int(pstat[3])},
+            'all_gather': gather,
         }
 
     # ---- extras on rank 0 at N == 1: BASELINE config 2 (ViT only, 32 tiles) and the CPU baseline ----

@@ -49,15 +49,50 @@ int ws_ensure(cr_ctx* c, size_t bytes) {
     return CR_OK;
 }
 
+// Measurement (cr_profile): one event pair per GEMM launch on the launch stream.  Records are retired into per-class
+// accumulators as soon as their second event has completed (events of one stream complete in order, so the queue is
+// drained from the front with a non-blocking hipEventQuery); nothing is ever dropped.  Only when more than
+// PROF_HARD records are still in flight (the host running that far ahead of the GPU) does the oldest one get waited for.
+static constexpr size_t PROF_SOFT = 256, PROF_HARD = 16384;
+
+static void prof_retire(cr_ctx* c, bool block_all) {
+    while (!c->prof_recs.empty()) {
+        cr_ctx::ProfRec& r = c->prof_recs.front();
+        hipError_t q = hipEventQuery(r.b);
+        if (q == hipErrorNotReady) {
+            if (!block_all && c->prof_recs.size() <= PROF_HARD) break;
+            q = hipEventSynchronize(r.b);
+        }
+        float ms = 0.f;
+        if (q == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            double* o = c->prof_acc[r.big ? 0 : 1];
+            o[0] += 1.0; o[1] += ms; o[2] += r.flops; o[3] += r.bytes;
+            c->prof_retired++;
+        } else {
+            (void)hipGetLastError();
+            c->prof_lost++;
+        }
+        c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
+        c->prof_recs.pop_front();
+    }
+}
+
 int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
     cr_ctx::ProfRec rec{};
-    const bool on = c->prof && (c->prof_mode != 2 || p.M >= 1024) && c->prof_recs.size() < 200000;
+    bool on = c->prof && (c->prof_mode != 2 || p.M >= 1024);
     if (on) {
-        for (hipEvent_t* e : {&rec.a, &rec.b}) {
-            if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
-            else if (hipEventCreate(e) != hipSuccess) return cr_fail(CR_ERR_HIP, "hipEventCreate");
+        if (c->prof_recs.size() >= PROF_SOFT) prof_retire(c, false);
+        hipEvent_t* ev[2] = {&rec.a, &rec.b};
+        for (int i = 0; i < 2 && on; i++) {
+            if (!c->prof_pool.empty()) { *ev[i] = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else if (hipEventCreate(ev[i]) != hipSuccess) {
+                (void)hipGetLastError();
+                if (i == 1) c->prof_pool.push_back(rec.a);       // keep the first event for the next launch
+                c->prof_lost++;
+                on = false;                                     // measure nothing for this launch, but do launch it
+            }
         }
-        hipEventRecord(rec.a, st);
+        if (on) hipEventRecord(rec.a, st);
     }
     const int r = launch_gemm(epi, p, st);
     if (on) {
@@ -67,6 +102,8 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
         rec.bytes = 2.0 * ((double)p.N * p.K + (double)p.M * p.K) + (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out;
         rec.big = p.M >= 1024;
         c->prof_recs.push_back(rec);
+        c->prof_issued++;
+        if ((int64_t)c->prof_recs.size() > c->prof_peak_pending) c->prof_peak_pending = (int64_t)c->prof_recs.size();
     }
     if (r != CR_OK) return cr_fail(r, "gemm(epi=%d M=%d N=%d K=%d) rejected or failed to launch", epi, p.M, p.N, p.K);
     return CR_OK;
@@ -143,16 +180,15 @@ int cr_profile(cr_ctx* c, int enable) {
 int cr_profile_read(cr_ctx* c, double* out) {
     if (!c || !out) return cr_fail(CR_ERR_ARG, "cr_profile_read: null argument");
     CR_HIP(hipSetDevice(c->device));
-    CR_HIP(hipDeviceSynchronize());
-    for (int i = 0; i < 8; i++) out[i] = 0.0;
-    for (auto& r : c->prof_recs) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
-        double* o = out + (r.big ? 0 : 4);
-        o[0] += 1.0; o[1] += ms; o[2] += r.flops; o[3] += r.bytes;
-        c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
-    }
-    c->prof_recs.clear();
+    prof_retire(c, true);
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < 4; i++) { out[k * 4 + i] = c->prof_acc[k][i]; c->prof_acc[k][i] = 0.0; }
+    return CR_OK;
+}
+
+int cr_profile_stats(cr_ctx* c, int64_t* out) {
+    if (!c || !out) return cr_fail(CR_ERR_ARG, "cr_profile_stats: null argument");
+    out[0] = c->prof_issued; out[1] = c->prof_retired + (int64_t)c->prof_recs.size(); out[2] = c->prof_lost; out[3] = c->prof_peak_pending;
     return CR_OK;
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -14,6 +16,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define CR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
 #include "../../include/callireader_hip.h"   // error codes of the C ABI
+
+// ---- per-DEVICE one-time launch set-up (host) -------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize and the CU count belong to a device, not to the process: a launcher keeps
+// one bit per device (the calling thread's current device) in a function-local atomic; setting the attribute twice
+// from two threads is harmless, so no lock is needed.  Returns false when the HIP call fails.
+inline bool cr_dyn_lds_once(std::atomic<uint64_t>& done, const void* fn, int lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+inline int cr_device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev & 63].store(n, std::memory_order_relaxed);
+    return n;
+}
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }      // RNE, NaN-preserving (v_cvt_pk_bf16_f32)

@@ -1,6 +1,7 @@
 // Context of libcallireader_hip.so: weights (library-owned device copies), derived
 // tensors, a grow-only device workspace.  Host-side C++ only; no torch types.
 #pragma once
+#include <deque>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -36,8 +37,10 @@ struct cr_ctx {
     // measurement (cr_profile): event pairs around GEMM launches
     bool prof = false;
     struct ProfRec { hipEvent_t a, b; double flops, bytes; int big; };
-    std::vector<ProfRec> prof_recs;
+    std::deque<ProfRec> prof_recs;      // launches whose events have not been read back yet (bounded: see ctx_gemm)
     std::vector<hipEvent_t> prof_pool;
+    double prof_acc[2][4] = {};         // [tiled M >= 1024 | the rest][launches, ms, flops, bytes] of the retired records
+    int64_t prof_issued = 0, prof_retired = 0, prof_lost = 0, prof_peak_pending = 0;
 };
 
 // GEMM launch used by every stage: validates, launches, and (when profiling) brackets the launch with events.

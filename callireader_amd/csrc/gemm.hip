@@ -125,12 +125,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
 template <int EPI>
 int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return CR_ERR_HIP;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm128_kernel<EPI>, LDS_BYTES)) return CR_ERR_HIP;
     hipLaunchKernelGGL(gemm128_kernel<EPI>, dim3(ntm * ntn), dim3(256), LDS_BYTES, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }

@@ -397,17 +397,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 template <int EPI>
 int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
-    static int n_cu = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess)
-            return CR_ERR_HIP;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CR_ERR_HIP;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm256_kernel<EPI>, LDS_BYTES2)) return CR_ERR_HIP;
+    const int n_cu = cr_device_cus();
     hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }

@@ -421,12 +421,23 @@ int cr_kv_free(cr_kv* kv) {
 
 int cr_kv_length(const cr_kv* kv, int seq) { return (kv && seq >= 0 && seq < kv->n_seqs) ? kv->len[seq] : -1; }
 
-int cr_kv_reset(cr_kv* kv, int seq) {
-    if (!kv || seq < 0 || seq >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_kv_reset: bad sequence");
-    CR_HIP(hipDeviceSynchronize());
-    CR_HIP(hipMemset(kv->d_len + seq, 0, 4));
-    CR_HIP(hipMemset(kv->d_ngen + seq, 0, 4));
-    kv->len[seq] = 0; kv->ngen[seq] = 0;
+int cr_kv_reset(cr_kv* kv, int seq, void* stream) {
+    if (!kv || seq >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_kv_reset: bad sequence");
+    CR_HIP(hipSetDevice(kv->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int s0 = seq < 0 ? 0 : seq, n = seq < 0 ? kv->n_seqs : 1;
+    CR_HIP(hipMemsetAsync(kv->d_len + s0, 0, (size_t)n * 4, st));
+    CR_HIP(hipMemsetAsync(kv->d_ngen + s0, 0, (size_t)n * 4, st));
+    for (int s = s0; s < s0 + n; s++) { kv->len[s] = 0; kv->ngen[s] = 0; }
+    return CR_OK;
+}
+
+int cr_kv_read(cr_kv* kv, int layer, int seq, int pos, int which, void* out, void* stream) {
+    if (!kv || !out || layer < 0 || layer >= kv->layers || seq < 0 || seq >= kv->n_seqs || pos < 0 || pos >= kv->max_tokens || (which != 0 && which != 1))
+        return cr_fail(CR_ERR_ARG, "cr_kv_read: bad argument");
+    CR_HIP(hipSetDevice(kv->ctx->device));
+    const bf16* base = (which ? kv->v : kv->k) + (((int64_t)layer * kv->n_seqs + seq) * NKV * kv->max_tokens + pos) * HD;
+    CR_HIP(hipMemcpy2DAsync(out, HD * 2, base, (size_t)kv->max_tokens * HD * 2, HD * 2, NKV, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CR_OK;
 }
 

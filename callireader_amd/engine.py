@@ -213,8 +213,15 @@ class KVCache:
     def length(self, seq):
         return B.lib.cr_kv_length(self._h, seq)
 
-    def reset(self, seq):
-        B.check(B.lib.cr_kv_reset(self._h, seq), 'cr_kv_reset')
+    def reset(self, seq=-1):
+        """Forget one sequence, or all of them (seq < 0); enqueued on the current stream."""
+        B.check(B.lib.cr_kv_reset(self._h, seq, _stream()), 'cr_kv_reset')
+
+    def read(self, layer, seq, pos, which=0):
+        """(8, 128) bf16: K (which=0, after RoPE) or V (which=1) of one cached position, all KV heads."""
+        out = torch.empty(8, 128, device=self.eng.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_kv_read(self._h, layer, seq, pos, which, _p(out), _stream()), 'cr_kv_read')
+        return out
 
     def generated(self, seq, max_tokens=4096):
         buf = (C.c_int64 * max_tokens)()

@@ -365,8 +365,7 @@ class InternVLChatModel:
             self.max_pages = max(P, self.max_pages)
             self._kv = self.engine.kv_alloc(self.max_pages, self.max_tokens)
         kv = self._kv
-        for i in range(P):
-            kv.reset(i)
+        kv.reset()
         for i0 in range(0, P, prefill_batch):                       # prompts of several pages share the linear layers' GEMMs
             idx = list(range(i0, min(P, i0 + prefill_batch)))
             self.engine.prefill_batch(kv, idx, [embeds_list[i] for i in idx], penalty=repetition_penalty)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 2   /* 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7) */
+#define CR_ABI_VERSION 3   /* 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3 };
@@ -110,7 +110,12 @@ int cr_embed_splice(cr_ctx* ctx, const int64_t* ids, int S, const void* vit_embe
 int cr_kv_alloc(cr_ctx* ctx, int n_seqs, int max_tokens, cr_kv** out);
 int cr_kv_free(cr_kv* kv);
 int cr_kv_length(const cr_kv* kv, int seq);           /* tokens currently cached (host-side bookkeeping) */
-int cr_kv_reset(cr_kv* kv, int seq);                  /* forget the sequence: length 0, no generated ids */
+/* Forget sequence `seq` (length 0, no generated ids), or every sequence when seq < 0.  Enqueued on `stream`, no
+ * device-wide synchronisation: ordered after earlier work on that stream and before what the caller enqueues next. */
+int cr_kv_reset(cr_kv* kv, int seq, void* stream);
+/* One cached position as the reference's tuple cache holds it (InternVL/modeling_internlm2.py:383-388, K after RoPE):
+ * out [8 kv heads][128] bf16 (device) = past_key_values[layer][which][seq, :, pos, :]; which 0 = K, 1 = V.  Parity tests. */
+int cr_kv_read(cr_kv* kv, int layer, int seq, int pos, int which, void* out, void* stream);
 /* Copy the ids generated so far for `seq` into host memory (at most `max`); returns the count, or < 0.
  * Synchronises `stream`. */
 int cr_kv_generated(cr_kv* kv, int seq, int64_t* out_host, int max, void* stream);
@@ -145,6 +150,10 @@ int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int6
  * whose launches cannot carry events). */
 int cr_profile(cr_ctx* ctx, int enable);
 int cr_profile_read(cr_ctx* ctx, double* out8);
+/* Bookkeeping of the above since cr_create: out[0] = launches bracketed, out[1] = launches accounted for (retired into
+ * the sums or still pending), out[2] = launches whose events could not be created or read (0 in a healthy run),
+ * out[3] = most records ever pending at once.  Records are retired as their events complete; there is no cap. */
+int cr_profile_stats(cr_ctx* ctx, int64_t* out4);
 
 /* ---- ordering front end ------------------------------------------------------------- */
 /* OrderFormer.model forward -- models/model.py:206-233, called from predict :458-461.

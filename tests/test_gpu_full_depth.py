@@ -1,0 +1,248 @@
+"""FULL-DEPTH parity on a real MI355X against vectors the REFERENCE itself produced.
+
+tests/golden/full_depth.npz was written in the build container by scripts/make_golden_full_depth.py, which imports the
+reference's own classes from /root/reference: InternVisionModel (24 layers) + InternVLChatModel.extract_feature on 2
+tiles, and InternLM2ForCausalLM (32 layers, 92 553-row vocabulary, eager attention) on a 300-token prompt followed by
+8 greedy steps of a hand loop over `forward`.  Weights are the seeded `callireader_amd.synthetic` tensors, regenerated
+here bit for bit on the CPU and uploaded.  The file also holds the reference's OWN bf16-vs-fp32 difference at these
+depths (same modules cast to fp32, same bf16 weight values), which is what the tolerances below are stated against:
+a second bf16 implementation with another accumulation order cannot sit closer to the bf16 reference than the bf16
+reference sits to exact arithmetic.
+
+Token bar: the HIP path's free-running greedy ids must equal the reference's.  A difference is only accepted at a step
+where the reference's own top-2 margin is below the measured logit difference bound (a tie the reference itself would
+resolve differently under any re-association), and then the test prints the step and that margin and walks on
+teacher-forced.  Everything measured is written to profiles/round2/full_depth_parity.json (gpurun_out/ on the GPU box
+as well) so the numbers quoted in DESIGN.md have an artifact.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from callireader_amd.config import ModelDims
+from callireader_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'full_depth.npz')
+RESULTS = {}
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm())
+
+
+def subsample(t, step, n):
+    return t.detach().float().reshape(-1)[::step][:n]
+
+
+def bits_to_f32(u16):
+    return torch.from_numpy(u16.astype(np.int32) << 16).view(torch.float32)
+
+
+def _dump():
+    for d in (os.path.join(ROOT, 'profiles', 'round2'), os.path.join(ROOT, 'gpurun_out')):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, 'full_depth_parity.json'), 'w') as f:
+                json.dump(RESULTS, f, indent=1)
+        except OSError:
+            pass
+
+
+@pytest.fixture(scope='module')
+def gold():
+    g = np.load(GOLD)
+    meta = json.loads(bytes(g['meta']).decode())
+    assert meta['seed'] == 0 and meta['tiles'] == 2
+    return g, meta
+
+
+@pytest.fixture(scope='module')
+def engine():
+    from callireader_amd.engine import Engine
+    dims = ModelDims.full()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    eng = Engine(dims, max_pos=1024)
+    t0 = time.time()
+    for parts in (('vit', 'mlp1'), ('llm',)):
+        for k, v in synthetic.iter_state_dict(dims, parts=parts, seed=0):     # CPU draw == the golden script's weights
+            eng.load_weight(k, v)
+    eng.load_rope()
+    eng.finalize()
+    RESULTS['weights_s'] = round(time.time() - t0, 1)
+    yield eng
+    eng.close()
+
+
+def test_vit_24_layers_and_projector_vs_reference(gold, engine):
+    g, meta = gold
+    px = synthetic.make_pixels(2, seed=meta['pixels_seed'])
+    last = engine.vit_forward(px.cuda())
+    feat = engine.extract_feature(px.cuda())
+    torch.cuda.synchronize()
+    noise = float(g['vit24.ref_bf16_vs_fp32_rel_l2'])           # the reference against itself in fp32
+    out = {}
+    for name, t in (('last', last), ('feat', feat)):
+        ref = torch.from_numpy(g[f'vit24.{name}.sample'])
+        got = subsample(t.cpu(), int(g[f'vit24.{name}.step']), ref.numel())
+        assert int(g[f'vit24.{name}.numel']) == t.numel()
+        out[name] = {'rel_l2': rel_l2(got, ref), 'max_abs': float((got - ref).abs().max()), 'ref_max_abs': float(ref.abs().max()),
+                     'sum_rel': abs(float(t.double().sum().item()) - float(g[f'vit24.{name}.sum'])) / float(g[f'vit24.{name}.abssum'])}
+    rows = torch.from_numpy(g['vit24.feat_rows'])
+    out['feat_rows_rel_l2'] = rel_l2(feat[:, :4, :].float().cpu(), rows)
+    out['reference_bf16_vs_fp32_rel_l2'] = noise
+    RESULTS['vit24'] = out
+    _dump()
+    print('full-depth vision:', json.dumps(out))
+    assert torch.isfinite(feat.float()).all()
+    # bound = the reference's own bf16 noise at this depth (1.25e-2 measured by the golden script); the HIP path
+    # measured 5e-3..7e-3
+    assert out['feat']['rel_l2'] <= noise, out
+    assert out['last']['rel_l2'] <= noise, out
+    assert out['feat_rows_rel_l2'] <= noise, out
+    assert out['feat']['sum_rel'] <= 2e-3 and out['last']['sum_rel'] <= 2e-3, out
+
+
+def test_llm_32_layers_full_vocab_vs_reference(gold, engine):
+    g, meta = gold
+    S, steps = meta['prompt_tokens'], meta['steps']
+    gen = torch.Generator().manual_seed(meta['prompt_seed'])
+    emb = (torch.randn(1, S, 4096, generator=gen) * 0.02).to(torch.bfloat16)
+    ref_logits = bits_to_f32(g['llm32.logits_bf16_bits'])       # [steps + 1][vocab]
+    ref_ids = g['llm32.greedy_tokens'].tolist()
+    margins = g['llm32.top2_margin'].tolist()
+    noise_l2, noise_abs = float(g['llm32.ref_bf16_vs_fp32_rel_l2']), float(g['llm32.ref_bf16_vs_fp32_max_abs'])
+    assert ref_logits.shape == (steps + 1, ModelDims.full().vocab)
+
+    # (1) free-running greedy: prefill + `steps` decode steps, nothing forced
+    kv = engine.kv_alloc(1, 512)
+    engine.prefill(kv, 0, emb.cuda())
+    for _ in range(steps):
+        engine.decode(kv, [0])
+    free_ids = kv.generated(0)[:steps + 1]
+    first_div = next((i for i, (a, b) in enumerate(zip(free_ids, ref_ids)) if a != b), None)
+
+    # (2) teacher-forced along the reference's ids: every step's logits against the reference's
+    kv.reset(0)
+    lg = engine.prefill(kv, 0, emb.cuda(), want_logits=True)
+    per_step, picks = [], []
+    for t in range(steps + 1):
+        got, ref = lg.float().cpu().reshape(-1), ref_logits[t]
+        picked = kv.generated(0)[t]
+        picks.append(picked)
+        per_step.append({'rel_l2': rel_l2(got, ref), 'max_abs': float((got - ref).abs().max()),
+                         'ref_margin': margins[t], 'ref_id': ref_ids[t], 'hip_id': picked,
+                         'hip_gap_at_ref_ids': float(got[picked] - got[ref_ids[t]])})
+        if t < steps:
+            lg = engine.decode(kv, [0], force_tokens=torch.tensor([ref_ids[t]]), want_logits=True)
+    torch.cuda.synchronize()
+    # KV rows the reference kept
+    out = {'prompt_tokens': S, 'steps': steps, 'reference_ids': ref_ids, 'hip_free_running_ids': free_ids,
+           'first_divergence': first_div, 'per_step': per_step,
+           'reference_bf16_vs_fp32': {'rel_l2': noise_l2, 'max_abs': noise_abs},
+           'worst_rel_l2': max(p['rel_l2'] for p in per_step), 'worst_max_abs': max(p['max_abs'] for p in per_step)}
+    RESULTS['llm32'] = out
+    _dump()
+    print('full-depth LLM:', json.dumps({k: v for k, v in out.items() if k != 'per_step'}))
+    for t, p in enumerate(per_step):
+        print(f'  step {t}: rel-L2 {p["rel_l2"]:.3e} max|d| {p["max_abs"]:.3f} ref id {p["ref_id"]} (margin {p["ref_margin"]:.4f}) hip id {p["hip_id"]}')
+    # logits: within the reference's own bf16-vs-fp32 noise at this depth
+    assert out['worst_rel_l2'] <= noise_l2, out['worst_rel_l2']
+    assert out['worst_max_abs'] <= max(noise_abs, 0.12), out['worst_max_abs']
+    # tokens: exact, or a reference near-tie (margin below the logit difference actually measured at that step)
+    for t, p in enumerate(per_step):
+        if p['hip_id'] != p['ref_id']:
+            print(f'  greedy pick differs at step {t}: reference margin {p["ref_margin"]:.4f}, logit |d| bound {p["max_abs"]:.4f}')
+            assert p['ref_margin'] <= 2 * p['max_abs'], (t, p)
+    if first_div is None:
+        assert free_ids == ref_ids
+    else:
+        assert per_step[first_div]['hip_id'] != per_step[first_div]['ref_id'], 'free-running and teacher-forced picks disagree'
+    kv.free()
+
+
+def test_llm_kv_rows_vs_reference(gold, engine):
+    """K of layer 0 at the last prompt position (after RoPE at position 299) and V of layer 31 at position 0, as the
+    reference's tuple cache holds them (modeling_internlm2.py:383-388); and prefill is deterministic."""
+    g, meta = gold
+    S = meta['prompt_tokens']
+    gen = torch.Generator().manual_seed(meta['prompt_seed'])
+    emb = (torch.randn(1, S, 4096, generator=gen) * 0.02).to(torch.bfloat16)
+    kv = engine.kv_alloc(2, 512)
+    a = engine.prefill(kv, 0, emb.cuda(), want_logits=True)
+    b = engine.prefill(kv, 1, emb.cuda(), want_logits=True)
+    k0 = kv.read(0, 1, S - 1, 0).float().cpu()
+    v31 = kv.read(31, 1, 0, 1).float().cpu()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), 'prefill is not deterministic'
+    rk, rv = torch.from_numpy(g['llm32.k0_last']), torch.from_numpy(g['llm32.v31_first'])
+    out = {'k_layer0_last_rel_l2': rel_l2(k0, rk), 'v_layer31_first_rel_l2': rel_l2(v31, rv)}
+    RESULTS['llm32_kv'] = out
+    _dump()
+    print('full-depth KV rows:', out)
+    assert out['k_layer0_last_rel_l2'] <= 1e-2, out          # layer 0: one RMSNorm + GEMM + RoPE deep
+    assert out['v_layer31_first_rel_l2'] <= float(g['llm32.ref_bf16_vs_fp32_rel_l2']) * 2, out   # 31 layers of residual stream behind it
+    kv.free()
+
+
+def test_llm_extra_prompts_token_agreement(gold, engine):
+    """Two more prompts (64 and 513 tokens, 12 greedy steps each), teacher-forced along the reference's ids: per step the
+    reference's top-16 logits and a stride-8 sample of the row are compared, and the greedy pick is counted."""
+    g, meta = gold
+    noise_l2 = float(g['llm32.ref_bf16_vs_fp32_rel_l2'])
+    summary = []
+    for i, (seed, tokens, steps) in enumerate(meta['extra_prompts']):
+        tag = f'llm32.extra{i}'
+        gen = torch.Generator().manual_seed(seed)
+        emb = (torch.randn(1, tokens, 4096, generator=gen) * 0.02).to(torch.bfloat16)
+        ref_ids, margins = g[f'{tag}.greedy_tokens'].tolist(), g[f'{tag}.top2_margin'].tolist()
+        top_ids, top_val = torch.from_numpy(g[f'{tag}.top16_ids']), torch.from_numpy(g[f'{tag}.top16_logits'])
+        strided = bits_to_f32(g[f'{tag}.logits_stride8_bf16_bits'])
+        kv = engine.kv_alloc(1, 1024)
+        lg = engine.prefill(kv, 0, emb.cuda(), want_logits=True)
+        rows = []
+        for t in range(steps + 1):
+            got = lg.float().cpu().reshape(-1)
+            picked = kv.generated(0)[t]
+            rows.append({'rel_l2_stride8': rel_l2(got[::8], strided[t]), 'max_abs_top16': float((got[top_ids[t]] - top_val[t]).abs().max()),
+                         'max_abs_stride8': float((got[::8] - strided[t]).abs().max()),
+                         'ref_id': ref_ids[t], 'hip_id': picked, 'ref_margin': margins[t]})
+            if t < steps:
+                lg = engine.decode(kv, [0], force_tokens=torch.tensor([ref_ids[t]]), want_logits=True)
+        torch.cuda.synchronize()
+        kv.free()
+        agree = sum(r['ref_id'] == r['hip_id'] for r in rows)
+        summary.append({'prompt_tokens': tokens, 'steps': steps, 'picks_equal': agree, 'picks': len(rows),
+                        'worst_rel_l2': max(r['rel_l2_stride8'] for r in rows), 'worst_max_abs': max(r['max_abs_stride8'] for r in rows),
+                        'differing': [{'step': t, **r} for t, r in enumerate(rows) if r['ref_id'] != r['hip_id']]})
+        for t, r in enumerate(rows):
+            assert r['rel_l2_stride8'] <= noise_l2, (tag, t, r)
+            if r['ref_id'] != r['hip_id']:
+                print(f'  {tag} step {t}: pick differs, reference margin {r["ref_margin"]:.4f}, |d| on this row {r["max_abs_stride8"]:.4f}')
+                assert r['ref_margin'] <= 2 * max(r['max_abs_stride8'], r['max_abs_top16']), (tag, t, r)
+    RESULTS['llm32_extra'] = summary
+    _dump()
+    print('full-depth LLM, extra prompts:', json.dumps(summary))
+
+
+def test_vit_config2_properties(engine):
+    """BASELINE config 2 at full size (32 tiles, 24 layers): finite, deterministic, and invariant to how the tiles are
+    chunked -- 32 at once == 31 + 1 == 16 + 16, bit for bit (a tile's result never depends on its batch)."""
+    px = synthetic.make_pixels(32, seed=0).cuda()
+    full = engine.vit_forward(px)
+    again = engine.vit_forward(px)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full.float()).all()
+    assert torch.equal(full, again)
+    a = torch.cat([engine.vit_forward(px[:31]), engine.vit_forward(px[31:])])
+    b = torch.cat([engine.vit_forward(px[:16]), engine.vit_forward(px[16:])])
+    torch.cuda.synchronize()
+    assert torch.equal(full, a) and torch.equal(full, b)
+    RESULTS['vit_config2_properties'] = {'tiles': 32, 'finite': True, 'deterministic': True, 'chunking_invariant': True}
+    _dump()
