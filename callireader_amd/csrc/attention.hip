@@ -17,9 +17,11 @@
 //   LLM  (modeling_internlm2.py:393-410): scores rounded to bf16, divided by sqrt(d) -> bf16,
 //        causal mask, fp32 softmax, probabilities cast to bf16 before .V (we cast the
 //        un-normalised exp and divide the fp32 accumulator by the fp32 row sum at the end).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "attention.hpp"
 
@@ -37,6 +39,17 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ float lo_bf16(unsigned pk) { return __uint_as_float(pk << 16); }
 __device__ __forceinline__ float hi_bf16(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+// round_bf16(x) as an fp32 value in ONE instruction: v_cvt_pk_bf16_f32 (0, x) -- the low half of the result is
+// bf16(0) = 0x0000, so the dword is the rounded value itself (no unpacking shift / mask)
+__device__ __forceinline__ float rbf1(float x) {
+    const f32x2_t v = {0.f, x};
+    return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)));
+}
+
+#ifndef CR_ATTN_LEAN
+#define CR_ATTN_LEAN 1
+#endif
 
 template <int D> __device__ __forceinline__ int kswz(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
 template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2); }
@@ -196,6 +209,29 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         // row maximum is taken on the raw accumulators (rounding is monotonic, so max(round(s)) = round(max(s))) with
         // v_max3_f32.  Masking only on tiles that need it.
         const bool need_mask = (kt * 64 + 64 > Sk) || (CAUSAL && kt * 64 + 63 > p.q_pos0 + qb * 128 + wave * 32);
+        unsigned ppk[2][8];                                   // P as packed bf16 pairs: the PV B-operand, 4 dwords per fragment
+        // Lean form for unmasked tiles after the first (no mask, no divisor: the ViT): the reference point of exp(s - m)
+        // stays where the first tile put it (<= the true row maximum); P is rounded to bf16, which has fp32's exponent
+        // range, and accumulated in fp32, so nothing is lost while P is finite.  Per score: one v_cvt_pk_bf16_f32 (0, s)
+        // rounds it in place, one FMA, one v_exp_f32, half a packed add, half a v_cvt_pk -- no v_max3, no unpacking.  A
+        // row sum >= 2^60 in any lane (a score ~42 above the reference point, or +inf) falls back to the exact form below.
+        bool lean_done = false;
+        if (CR_ATTN_LEAN && !CAUSAL && !DIV && kt > t_begin && !need_mask) {
+            const float m2f = m_run * LOG2E;
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sacc[kb][2 * i]), LOG2E, -m2f));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sacc[kb][2 * i + 1]), LOG2E, -m2f));
+                    q0 += p0; q1 += p1;
+                    ppk[kb][i] = pack_bf16(p0, p1);
+                }
+            const float qs = q0 + q1;
+            if (__all(qs < 1.152921504606846976e18f)) { l_run += qs; lean_done = true; }
+        }
+        if (!lean_done) {
         float mraw = -INFINITY;
         unsigned spk[2][8];
         auto score_pass = [&](auto masked) {
@@ -229,7 +265,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         // exponentials on pairs: packed fp32 math (v_pk_fma_f32 / v_pk_add_f32) halves the FMA and row-sum issue slots
         f32x2_t psum2 = {0.f, 0.f};
         const f32x2_t l2e = {LOG2E, LOG2E}, negm = {-m2, -m2};
-        unsigned ppk[2][8];                                   // P as packed bf16 pairs: the PV B-operand, 4 dwords per fragment
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             for (int db = 0; db < DB; db++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+        }
         }
 
         // ---- O^T += V^T . P^T ----
@@ -304,52 +340,43 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 }
 
 // ---- ViT attention (d = 64, no mask, no score divisor), software-pipelined over 32-key halves ------------------------
-// The kernel above runs K.Q^T -> softmax -> P.V of a tile back to back in every wave: each stage waits for the one
-// before it (round-1 counters: per wave and 64-key tile ~945 cycles of vector issue + 512 of MFMA + ~200 of LDS/scalar
-// issue ADD UP to the ~1690 observed).  At d = 64 the softmax is the long pole (32 scores per lane and tile at ~6 vector
-// issue slots each against 16 MFMAs), so here every wave keeps its vector stream busy and sprinkles the MFMAs of OTHER
-// halves into it:
-//   half-iteration h:   vector: softmax of half h (scores S_h computed one half-iteration ago)
-//                       matrix: S_{h+1} = K_{h+1} . Q^T (4 MFMAs)  and  O += V_{h-1}^T . P_{h-1} (4 MFMAs)
-// Nothing a half-iteration issues depends on what it issues itself, so neither pipe waits for the other; the two or
-// three waves of a SIMD fill each other's issue gaps.  S and P live in two named register sets (even / odd half).
-// K tiles ride a 3-slot LDS ring two tiles ahead, V tiles a 3-slot ring one tile ahead (a half-iteration of tile t reads
-// K(t), K(t+1), V(t-1), V(t)); one workgroup barrier per 64-key tile.  Rounding points as above
-// (modeling_intern_vit.py:225-229).  The O / l rescale of the online softmax is deferred (threshold 8) and applied at
-// the end of the half-iteration that decided it, after the P.V of the previous half (whose P is at the old maximum).
-#ifndef CR_ATTN_VIT_SCHED
-#define CR_ATTN_VIT_SCHED 1      // 0: program order left to the compiler; 1: MFMAs spaced through the vector stream
-#endif
-
-// 1 KiB LDS-DMA piece issued from inline asm: hipcc keeps no count of it, so it neither drains the ring with a
-// vmcnt(0) in front of the next LDS read (it cannot tell the slots apart) nor at a barrier; the kernel waits for its own
-// DMA once per tile, right before the barrier that publishes the tile.  M0 is saved and restored inside the statement.
-__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
+// The generic kernel above runs K.Q^T -> softmax -> P.V of a tile back to back in every wave.  At d = 64 the softmax is
+// the long pole: 32 scores per lane and 64-key tile against 16 MFMAs, and the vector pipe, not the matrix pipe, sets the
+// time (measured per SIMD with scripts/ubench/valu_issue.hip at two waves per SIMD: plain fp32 op 2.4-2.7 cycles,
+// v_cvt_pk_bf16_f32 / v_max3 3.5, v_exp_f32 6.5; round-1 counters: ~7.2 vector instructions per score).  So this kernel
+// (a) keeps every wave's vector stream free of waits: a half-iteration issues the softmax of half h next to the MFMAs of
+//     OTHER halves,  S_{h+1} = K_{h+1} . Q^T (4 MFMAs)  and  O += V_{h-1}^T . P_{h-1} (4 MFMAs); S and P live in two named
+//     register sets (even / odd half);
+// (b) spends fewer vector instructions per score:
+//     * bf16 rounding of a score straight to an fp32 register with ONE v_cvt_pk_bf16_f32 (0, s): the low half of the
+//       result is bf16(0) = 0x0000, so the dword IS round_bf16(s) as fp32 -- no unpacking shifts/masks;
+//     * no running maximum in the steady state: the reference point m of exp(s - m) is the row maximum of the FIRST
+//       half (always <= the true maximum), P = 2^((s - m) log2 e) is rounded to bf16 (which has fp32's exponent range)
+//       and accumulated in fp32, so nothing is lost while P stays finite; a half whose row sum reaches 2^60 (any lane:
+//       wave-uniform vote) is redone on the spot with the exact maximum and the usual O / l rescale.  Same value of
+//       softmax(s) . V up to the rounding of P; the reference's rounding points (modeling_intern_vit.py:225-229: q*scale
+//       in bf16, scores in bf16, fp32 softmax, bf16 probabilities into .V) are kept;
+// (c) stages K/V through registers (global_load_dwordx4 -> ds_write_b128 one tile later, T14 of the guide): an LDS-DMA
+//     piece cost this loop ~140 cycles of issue (in-kernel stamps: 564 cycles per tile for 4 pieces, 20 % of the tile).
+// K tiles ride a 3-slot LDS ring two tiles ahead, V tiles a 3-slot ring one tile ahead (a tile's two half-iterations
+// read K(t), K(t+1), V(t-1), V(t)); one workgroup barrier per 64-key tile.
 struct VitLane {
     int koff[4];       // byte offset of K fragment ks inside a 32-key half (row part included)
     int voff[2];       // byte offset of the transposed V read of d-block db (row part included)
     int hh;
 };
 
-template <bool DO_QK, bool DO_PV, bool MASK>
+// FAST: steady-state form (reference point kept, overflow vote); otherwise the exact-maximum form (first half, edges)
+template <bool DO_QK, bool DO_PV, bool MASK, bool FAST>
 __device__ __forceinline__ void vit_half(f32x16& s_cur, f32x16& s_next, unsigned (&p_cur)[8], const unsigned (&p_prev)[8],
                                          f32x16 (&oacc)[2], float& m_run, float& l_run, const bf16x8 (&qf)[4],
                                          const char* k_next, const char* v_prev, const VitLane& ln, int key0, int Sk) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     // The vector stream is cut into eight pieces and one MFMA goes in front of each; sched_barrier(0) pins the pieces
-    // (CR_ATTN_VIT_SCHED == 0 leaves the order to the compiler, which clumps the MFMAs).
-#if CR_ATTN_VIT_SCHED == 1
+    // (left to itself the compiler clumps the MFMAs).
 #define VIT_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define VIT_PIN()
-#endif
     __builtin_amdgcn_sched_barrier(0);
-    // ---- matrix stream operands from LDS (consumed one half-iteration's worth of vector work later)
+    // ---- matrix stream operands from LDS
     bf16x8 kf[4];
     bf16x8 vf[2][2];
     if (DO_QK) {
@@ -385,68 +412,112 @@ __device__ __forceinline__ void vit_half(f32x16& s_cur, f32x16& s_next, unsigned
         if ((i & 1) == 0) { if (DO_QK) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j], acc, 0, 0, 0); }
         else { if (DO_PV) oacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j >> 1][j & 1], pf[j >> 1], oacc[j & 1], 0, 0, 0); }
     };
-    VIT_PIN();
-    // ---- piece 0: reference rounding of the scores (pairs, one v_cvt_pk_bf16_f32 each) and the row maximum on the raw
-    //      accumulators (rounding is monotonic); query = lane, keys key0 + (e&3) + 8*(e>>2) + 4*hh
-    mm(0);
-    float mraw = -INFINITY;
-    unsigned spk[8];
+    // scores of this half, query = lane, keys key0 + (e&3) + 8*(e>>2) + 4*hh
+    auto score = [&](int e) -> float {
+        float x = s_cur[e];
+        if (MASK) { const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * ln.hh; x = key < Sk ? x : -INFINITY; }
+        return x;
+    };
+    float m2, alpha = 1.0f;
+    bool rescale = false;
+    if (!FAST) {
+        // ---- exact form: row maximum on the raw accumulators (rounding is monotonic), across the two half-waves with
+        //      one v_permlane32_swap, deferred-rescale vote (threshold 8)
+        VIT_PIN();
+        mm(0);
+        float mraw = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-        float s0 = s_cur[e], s1 = s_cur[e + 1];
-        if (MASK) {
-            const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * ln.hh;
-            s0 = key < Sk ? s0 : -INFINITY;
-            s1 = key + 1 < Sk ? s1 : -INFINITY;
+        for (int e = 0; e < 16; e += 2) mraw = fmaxf(fmaxf(mraw, score(e)), score(e + 1));
+        VIT_PIN();
+        mm(1);
+        float mloc = rbf1(mraw);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+            mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        mraw = fmaxf(fmaxf(mraw, s0), s1);
-        spk[e >> 1] = pack_bf16(s0, s1);
+        rescale = !__all(mloc - m_run <= 8.0f);
+        const float m_new = rescale ? fmaxf(m_run, mloc) : m_run;
+        alpha = rescale ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
+        m_run = m_new;
+        VIT_PIN();
     }
-    VIT_PIN();
-    // ---- piece 1: maximum across the two half-waves (one v_permlane32_swap), deferred-rescale vote, new reference point
-    mm(1);
-    float mloc = lo_bf16(pack_bf16(mraw, mraw));
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
-        mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const bool rescale = !__all(mloc - m_run <= 8.0f);
-    const float m_new = rescale ? fmaxf(m_run, mloc) : m_run;
-    const float m2 = m_new * LOG2E;
-    const float alpha = rescale ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
-    m_run = m_new;
-    VIT_PIN();
-    // ---- pieces 2..7: exponentials, row sum, P packed to bf16 (the P.V B operand)
+    m2 = m_run * LOG2E;
+    // ---- exponentials of the bf16-rounded scores, row sum, P packed to bf16 (the P.V B operand)
     float ps0 = 0.f, ps1 = 0.f;
     auto expo = [&](int i) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(lo_bf16(spk[i]), LOG2E, -m2));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(hi_bf16(spk[i]), LOG2E, -m2));
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(score(2 * i)), LOG2E, -m2));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(score(2 * i + 1)), LOG2E, -m2));
         ps0 += p0; ps1 += p1;
         p_cur[i] = pack_bf16(p0, p1);
     };
-    mm(2); expo(0); VIT_PIN();
-    mm(3); expo(1); VIT_PIN();
-    mm(4); expo(2); expo(3); VIT_PIN();
-    mm(5); expo(4); VIT_PIN();
-    mm(6); expo(5); expo(6); VIT_PIN();
-    mm(7); expo(7);
-    l_run = l_run * alpha + (ps0 + ps1);
+    if (FAST) {
+        // the LDS operands were requested a moment ago: one piece of vector work goes first, then an MFMA per piece
+        VIT_PIN();
+        expo(0); VIT_PIN();
+        mm(0); expo(1); VIT_PIN();
+        mm(1); expo(2); VIT_PIN();
+        mm(2); expo(3); VIT_PIN();
+        mm(3); expo(4); VIT_PIN();
+        mm(4); expo(5); VIT_PIN();
+        mm(5); expo(6); VIT_PIN();
+        mm(6); expo(7); VIT_PIN();
+        mm(7);
+    } else {
+        mm(2); expo(0); VIT_PIN();
+        mm(3); expo(1); VIT_PIN();
+        mm(4); expo(2); expo(3); VIT_PIN();
+        mm(5); expo(4); VIT_PIN();
+        mm(6); expo(5); expo(6); VIT_PIN();
+        mm(7); expo(7);
+    }
+    float psum = ps0 + ps1;
     if (DO_QK) s_next = acc;
     __builtin_amdgcn_sched_barrier(0);
-    // the (rare, wave-uniform) rescale is tied to the END of the vector stream: left free, the compiler hoists the branch
-    // above the exponentials, which cuts the half-iteration in two and leaves the MFMAs in a clump of their own
-    int flag = rescale ? 1 : 0;
-    asm volatile("" : "+v"(flag), "+v"(l_run));
-    if (__builtin_amdgcn_readfirstlane(flag)) {        // P_{h-1} (already multiplied into O above) was at the old maximum
+    if (FAST) {
+        // a row sum of 2^60 or more (a score ~42 above the reference point), or an overflow to +inf, in ANY lane: redo
+        // this half with the exact maximum.  The flag is tied to the END of the vector stream (left free, the compiler
+        // hoists the branch above the exponentials and splits the half-iteration).
+        int bad = __all(psum < 1.152921504606846976e18f) ? 0 : 1;
+        asm volatile("" : "+v"(bad), "+v"(psum));
+        if (__builtin_amdgcn_readfirstlane(bad)) {
+            float mraw = -INFINITY;
 #pragma unroll
-        for (int db = 0; db < 2; db++)
+            for (int e = 0; e < 16; e++) mraw = fmaxf(mraw, score(e));
+            float mloc = rbf1(mraw);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            m_run = m_new;
+            m2 = m_new * LOG2E;
+            ps0 = 0.f; ps1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+            for (int i = 0; i < 8; i++) expo(i);
+            psum = ps0 + ps1;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; db++)          // P_{h-1} (already multiplied into O above) was at the old reference point
+#pragma unroll
+                for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+        }
+        l_run += psum;
+    } else {
+        l_run = l_run * alpha + psum;
+        int flag = rescale ? 1 : 0;
+        asm volatile("" : "+v"(flag), "+v"(l_run));
+        if (__builtin_amdgcn_readfirstlane(flag)) {
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+        }
     }
 #undef VIT_PIN
 }
 
-__global__ __launch_bounds__(256, 2) void vit_attn_kernel(const AttnParams p) {
+#ifndef CR_ATTN_VIT_WAVES
+#define CR_ATTN_VIT_WAVES 2
+#endif
+__global__ __launch_bounds__(256, CR_ATTN_VIT_WAVES) void vit_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB;      // 8 KiB per K or V tile
     constexpr int VBASE = 3 * TILE;
@@ -469,67 +540,82 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const AttnParams p) {
     const int qi = qb * 128 + wave * 32 + l31;
     const int qi_c = min(qi, p.Sq - 1);
     const bool active = qb * 128 + wave * 32 < p.Sq;          // wave-uniform: a wave of padding rows only stages
+#ifdef CR_ATTN_STAMPS
+    unsigned long long ph[6];
+#define PSTAMP(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PSTAMP(i)
+#endif
+    PSTAMP(0);
 
     const bf16* Kb = p.K + (int64_t)batch * p.k_bs + (int64_t)head * p.k_hs;
     const bf16* Vb = p.V + (int64_t)batch * p.v_bs + (int64_t)head * p.v_hs;
-
-    // staging: a wave fills rows 16*wave .. 16*wave+15 of a tile with two 1-KiB DMA pieces (8 rows x 128 B each);
-    // the 16-B chunk swizzles live on the SOURCE address, the LDS image is lane-linear
-    const int srow0 = wave * 16 + (lane >> 3);
-    const int scp = lane & 7;
-    const unsigned lds0 = (unsigned)(uintptr_t)CR_LDS(smem);
-    // per-lane source pointers of tile 0 are computed once; a full tile adds a wave-uniform offset, only the ragged last
-    // tile re-derives clamped rows
-    const bf16* kbase[2];
-    const bf16* vbase[2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ii++) {
-        const int r = srow0 + ii * 8;
-        kbase[ii] = Kb + (int64_t)r * p.k_rs + ((scp ^ kswz<D>(r)) * 8);
-        vbase[ii] = Vb + (int64_t)r * p.v_rs + ((scp ^ vswz<D>(r)) * 8);
-    }
-    auto stage = [&](const bf16* base, int64_t rs, int slot_off, int kt, bool is_v) {
-        const bool full = kt * 64 + 64 <= Sk;
-        const int64_t toff = (int64_t)kt * 64 * rs;              // scalar
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++) {
-            const bf16* src;
-            if (full) src = (is_v ? vbase[ii] : kbase[ii]) + toff;
-            else {
-                const int r = srow0 + ii * 8;
-                const int key = min(kt * 64 + r, Sk - 1);
-                const int sw = is_v ? vswz<D>(r) : kswz<D>(r);
-                src = base + (int64_t)key * rs + ((scp ^ sw) * 8);
-            }
-            glds16_asm(src, __builtin_amdgcn_readfirstlane(lds0 + slot_off + (wave * 2 + ii) * 1024));
-        }
-    };
-
     const int nt = (Sk + 63) / 64;
     const int NH = (Sk + 31) / 32;                            // 32-key halves that hold at least one key
     const bool ragged = (Sk & 31) != 0;
 
-    // ---- prologue: K(0), V(0), K(1) on their way, then the Q fragment (B operand of K.Q^T: lane (query l31, half hh)
-    //      holds Q[q][16ks + 8hh .. +7]), then ONE compiler-visible vmcnt(0): hipcc must know the Q loads have landed,
-    //      or it carries "Q may be pending" into the loop and puts counted vmcnt waits in front of the K.Q^T MFMAs --
-    //      which on the hardware counter wait for this kernel's own (asm, uncounted) DMA
-    stage(Kb, p.k_rs, 0, 0, false);
-    stage(Vb, p.v_rs, VBASE, 0, true);
-    if (nt > 1) stage(Kb, p.k_rs, TILE, 1, false);
+    // staging: a wave owns rows 16*wave .. 16*wave+15 of every tile, as two pieces of 8 rows x 128 B; lane -> (row
+    // lane>>3, 16-B chunk lane&7).  The chunk swizzles live on the SOURCE address, the LDS image is lane-linear.
+    const int srow0 = wave * 16 + (lane >> 3);
+    const int scp = lane & 7;
+    // per-lane source pointers of the tile being requested; a full tile later = one 64-bit add of a wave-uniform stride,
+    // only a ragged last tile (and requests past the end, which re-load the last tile and are never read) clamp rows
+    const bf16* kptr[2];
+    const bf16* vptr[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++) {
+        const int r = srow0 + ii * 8;
+        kptr[ii] = Kb + (int64_t)r * p.k_rs + ((scp ^ kswz<D>(r)) * 8);
+        vptr[ii] = Vb + (int64_t)r * p.v_rs + ((scp ^ vswz<D>(r)) * 8);
+    }
+    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
+    auto load_tile = [&](const bf16* (&ptr)[2], int64_t rs, int64_t step, int kt, bf16x8 (&r)[2]) {
+        if (kt * 64 + 64 <= Sk) {                             // wave-uniform
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) r[ii] = *(const bf16x8*)(ptr[ii] + (int64_t)kt * step);
+        } else {
+            const int kc = min(kt, nt - 1);
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) {
+                const int row = srow0 + ii * 8;
+                const int back = max(kc * 64 + row - (Sk - 1), 0);        // rows past the last key read the last key
+                r[ii] = *(const bf16x8*)(ptr[ii] + (int64_t)kc * step - (int64_t)back * rs);
+            }
+        }
+    };
+    char* my_piece = smem + wave * 2048 + lane * 16;
+    auto write_tile = [&](int slot_off, const bf16x8 (&r)[2]) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) *(bf16x8*)(my_piece + slot_off + ii * 1024) = r[ii];
+    };
+
+    // ---- prologue: K(0), V(0), K(1) into the rings; K(2) and V(1) on their way in the staging registers; Q fragment
+    //      (B operand of K.Q^T: lane (query l31, half hh) holds Q[q][16ks + 8hh .. +7])
+    bf16x8 kst[2], vst[2];
+    {
+        bf16x8 k0[2], v0[2], k1[2];
+        load_tile(kptr, p.k_rs, kstep, 0, k0);
+        load_tile(vptr, p.v_rs, vstep, 0, v0);
+        load_tile(kptr, p.k_rs, kstep, 1, k1);
+        write_tile(0, k0);
+        write_tile(VBASE, v0);
+        write_tile(TILE, k1);
+    }
     bf16x8 qf[4];
     {
         const bf16* qp = p.Q + (int64_t)batch * p.q_bs + (int64_t)qi_c * p.q_rs + (int64_t)head * p.q_hs + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-    if (p.q_prescale != 1.0f) {
+        if (p.q_prescale != 1.0f) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++)
+            for (int ks = 0; ks < 4; ks++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) qf[ks][e] = f2bf(bf2f(qf[ks][e]) * p.q_prescale);
+                for (int e = 0; e < 8; e++) qf[ks][e] = f2bf(bf2f(qf[ks][e]) * p.q_prescale);
+        }
     }
-    __builtin_amdgcn_s_barrier();
+    load_tile(kptr, p.k_rs, kstep, 2, kst);
+    load_tile(vptr, p.v_rs, vstep, 1, vst);
+    __syncthreads();
 
     VitLane ln;
     ln.hh = hh;
@@ -567,64 +653,90 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const AttnParams p) {
     }
     int ks_cur = 0, ks_nxt = TILE, ks_nn = 2 * TILE;          // K ring: slots of tiles t, t+1, t+2
     int vs_prev = VBASE + 2 * TILE, vs_cur = VBASE, vs_nxt = VBASE + TILE;   // V ring: tiles t-1, t, t+1
-    // one tile = its even half then its odd half; `edge` tiles (the first, and those holding one of the last two halves)
-    // pick the variant of each half at run time, the tiles in between run the steady-state pair with no decisions
-    auto tile_sync_stage = [&](int t) {
-        if (t > 0) {                                          // K(t+1), V(t) landed; every wave is done with K(t-1), V(t-2)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        if (t + 2 < nt) stage(Kb, p.k_rs, ks_nn, t + 2, false);
-        if (t + 1 < nt) stage(Vb, p.v_rs, vs_nxt, t + 1, true);
+    // tile t: barrier (every wave is done with K(t-1), V(t-2); last tile's ring writes are visible) -> even half ->
+    // ring writes + next requests -> odd half.  The staging registers (K(t+2), V(t+1), requested one tile ago) go into the
+    // slots the barrier freed, then K(t+3), V(t+2) are requested.  Writing between the halves instead of right behind the
+    // barrier spreads the waves' ds_write bursts (stamps: 262 cycles for 4 ds_write_b128 when all 8 waves of the CU write
+    // at once, LDS stores run at ~80 B/clk/CU) and is just as safe: neither half of tile t reads the two slots written.
+    auto tile_stage = [&](int t) {
+        write_tile(ks_nn, kst);
+        write_tile(vs_nxt, vst);
+        load_tile(kptr, p.k_rs, kstep, t + 3, kst);
+        load_tile(vptr, p.v_rs, vstep, t + 2, vst);
     };
     auto rotate = [&]() {
         { const int x = ks_cur; ks_cur = ks_nxt; ks_nxt = ks_nn; ks_nn = x; }
         { const int x = vs_prev; vs_prev = vs_cur; vs_cur = vs_nxt; vs_nxt = x; }
     };
-    auto edge_tile = [&](int t) {
+    // `edge` tiles (the first, and those holding one of the last two halves) pick the variant of each half at run time,
+    // the tiles in between run the steady-state pair with no decisions
+    auto edge_even = [&](int t) {           // softmax of S_A; S_B = K_{2t+1} . Q^T; O += V_{2t-1}^T . P_B
         const int h0 = 2 * t;
         const bool last_e = h0 == NH - 1;
         const char* k_e = smem + ks_cur + 32 * ROWB;          // half 2t+1: rows 32..63 of K(t)
         const char* v_e = smem + vs_prev + 32 * ROWB;         // half 2t-1: rows 32..63 of V(t-1)
-        // even half: softmax of S_A; S_B = K_{2t+1} . Q^T; O += V_{2t-1}^T . P_B
         if (!last_e) {
-            if (t == 0) vit_half<true, false, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
-            else vit_half<true, true, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
+            if (t == 0) vit_half<true, false, false, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
+            else vit_half<true, true, false, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
         } else if (ragged) {
-            if (t == 0) vit_half<false, false, true>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
-            else vit_half<false, true, true>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
+            if (t == 0) vit_half<false, false, true, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
+            else vit_half<false, true, true, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
         } else {
-            if (t == 0) vit_half<false, false, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
-            else vit_half<false, true, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
+            if (t == 0) vit_half<false, false, false, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
+            else vit_half<false, true, false, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, k_e, v_e, ln, h0 * 32, Sk);
         }
-        if (!last_e) {
-            // odd half: softmax of S_B; S_A = K_{2t+2} . Q^T (first rows of K(t+1)); O += V_{2t}^T . P_A
-            const bool last_o = h0 + 1 == NH - 1;
-            const char* k_o = smem + ks_nxt;
-            const char* v_o = smem + vs_cur;
-            if (!last_o) vit_half<true, true, false>(sB, sA, pB, pA, oacc, m_run, l_run, qf, k_o, v_o, ln, (h0 + 1) * 32, Sk);
-            else if (ragged) vit_half<false, true, true>(sB, sA, pB, pA, oacc, m_run, l_run, qf, k_o, v_o, ln, (h0 + 1) * 32, Sk);
-            else vit_half<false, true, false>(sB, sA, pB, pA, oacc, m_run, l_run, qf, k_o, v_o, ln, (h0 + 1) * 32, Sk);
-        }
+    };
+    auto edge_odd = [&](int t) {            // softmax of S_B; S_A = K_{2t+2} . Q^T (first rows of K(t+1)); O += V_{2t}^T . P_A
+        const int h1 = 2 * t + 1;
+        if (h1 > NH - 1) return;
+        const bool last_o = h1 == NH - 1;
+        const char* k_o = smem + ks_nxt;
+        const char* v_o = smem + vs_cur;
+        if (!last_o) vit_half<true, true, false, false>(sB, sA, pB, pA, oacc, m_run, l_run, qf, k_o, v_o, ln, h1 * 32, Sk);
+        else if (ragged) vit_half<false, true, true, false>(sB, sA, pB, pA, oacc, m_run, l_run, qf, k_o, v_o, ln, h1 * 32, Sk);
+        else vit_half<false, true, false, false>(sB, sA, pB, pA, oacc, m_run, l_run, qf, k_o, v_o, ln, h1 * 32, Sk);
     };
     const int t_mid_end = (NH - 3) >> 1;                      // last tile whose two halves are both followed by another half
     int t = 0;
-    tile_sync_stage(0);
-    if (active) edge_tile(0);
+    PSTAMP(1);
+    if (active) edge_even(0);
+    tile_stage(0);
+    if (active) edge_odd(0);
     rotate();
+    PSTAMP(2);
+#ifdef CR_ATTN_STAMPS
+    unsigned long long acc_top = 0, acc_even = 0, acc_odd = 0, acc_mid = 0;
+#define STAMP(x) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(x)
+#endif
     for (t = 1; t <= t_mid_end; t++) {
-        tile_sync_stage(t);
-        if (active) {
-            vit_half<true, true, false>(sA, sB, pA, pB, oacc, m_run, l_run, qf, smem + ks_cur + 32 * ROWB, smem + vs_prev + 32 * ROWB, ln, 0, Sk);
-            vit_half<true, true, false>(sB, sA, pB, pA, oacc, m_run, l_run, qf, smem + ks_nxt, smem + vs_cur, ln, 0, Sk);
-        }
+#ifdef CR_ATTN_STAMPS
+        unsigned long long s0, s1, s2, s3, s4;
+#endif
+        STAMP(s0);
+        __syncthreads();
+        STAMP(s1);
+        if (active) vit_half<true, true, false, true>(sA, sB, pA, pB, oacc, m_run, l_run, qf, smem + ks_cur + 32 * ROWB, smem + vs_prev + 32 * ROWB, ln, 0, Sk);
+        STAMP(s2);
+        tile_stage(t);
+        STAMP(s3);
+        if (active) vit_half<true, true, false, true>(sB, sA, pB, pA, oacc, m_run, l_run, qf, smem + ks_nxt, smem + vs_cur, ln, 0, Sk);
+        STAMP(s4);
+#ifdef CR_ATTN_STAMPS
+        acc_top += s1 - s0; acc_even += s2 - s1; acc_mid += s3 - s2; acc_odd += s4 - s3;
+#endif
         rotate();
     }
+    PSTAMP(3);
     for (; t < nt; t++) {
-        tile_sync_stage(t);
-        if (active) edge_tile(t);
+        __syncthreads();
+        if (active) edge_even(t);
+        tile_stage(t);
+        if (active) edge_odd(t);
         rotate();
     }
+    PSTAMP(4);
     // ---- the last half's P.V  (after the rotation above vs_prev holds tile nt-1)
     if (active) {
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -660,6 +772,16 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const AttnParams p) {
                 *(bf16x4*)(op + 32 * db + 8 * g4) = o;
             }
     }
+#ifdef CR_ATTN_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    PSTAMP(5);
+    if (p.part_o && lane == 0) {
+        unsigned long long* d = (unsigned long long*)p.part_o + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave) * 12;
+        d[0] = acc_top; d[1] = acc_mid; d[2] = acc_even; d[3] = acc_odd;
+        for (int i = 0; i < 5; i++) d[4 + i] = ph[i + 1] - ph[i];
+        d[9] = active ? 1 : 0;
+    }
+#endif
 }
 
 int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
@@ -667,6 +789,36 @@ int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};
     if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS)) return CR_ERR_HIP;
     dim3 grid((p.Sq + 127) / 128, p.H, p.B);
+#ifdef CR_ATTN_STAMPS
+    {   // diagnostic build only: per-wave cycle sums of the steady-state loop, printed as cycles per tile
+        static unsigned long long* dbg = nullptr;
+        const size_t n = (size_t)grid.x * grid.y * grid.z * 48;
+        static size_t cap = 0;
+        if (n > cap) { if (dbg) hipFree(dbg); hipMalloc((void**)&dbg, n * 8); cap = n; }
+        hipMemsetAsync(dbg, 0, n * 8, stream);
+        AttnParams q = p;
+        q.part_o = (float*)dbg;
+        hipLaunchKernelGGL(vit_attn_kernel, grid, dim3(256), LDS, stream, q);
+        hipStreamSynchronize(stream);
+        static int calls = 0;
+        if (++calls == 3) {
+            std::vector<unsigned long long> h(n);
+            hipMemcpy(h.data(), dbg, n * 8, hipMemcpyDeviceToHost);
+            double a[9] = {0}, ia[5] = {0}; size_t waves = 0, idle = 0;
+            for (size_t i = 0; i < n; i += 12) {
+                if (h[i + 9]) { for (int k = 0; k < 9; k++) a[k] += (double)h[i + k]; waves++; }
+                else { for (int k = 0; k < 5; k++) ia[k] += (double)h[i + 4 + k]; idle++; }
+            }
+            const int tiles = ((p.Sk + 31) / 32 - 3) / 2;
+            fprintf(stderr, "[attn stamps] active waves %zu, steady tiles per wave %d: cycles per tile: barrier %.0f, even half %.0f, ring writes + requests %.0f, odd half %.0f\n",
+                    waves, tiles, a[0] / waves / tiles, a[2] / waves / tiles, a[1] / waves / tiles, a[3] / waves / tiles);
+            fprintf(stderr, "[attn stamps] cycles per wave: prologue %.0f, tile 0 %.0f, steady loop %.0f, tail tiles %.0f, last P.V + store %.0f;  staging-only waves (%zu): %.0f %.0f %.0f %.0f %.0f\n",
+                    a[4] / waves, a[5] / waves, a[6] / waves, a[7] / waves, a[8] / waves, idle, ia[0] / (idle ? idle : 1), ia[1] / (idle ? idle : 1),
+                    ia[2] / (idle ? idle : 1), ia[3] / (idle ? idle : 1), ia[4] / (idle ? idle : 1));
+        }
+        return CR_OK;
+    }
+#endif
     hipLaunchKernelGGL(vit_attn_kernel, grid, dim3(256), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }

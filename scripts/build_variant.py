@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Development aid: build ab/lib<name>.so = the library with ONE source recompiled under extra flags (A/B runs select it
+with CR_HIP_LIB=ab/lib<name>.so).  usage: build_variant.py <name> <source.hip> [-DFOO=1 ...]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from callireader_amd import build as B  # noqa: E402
+
+name, src = sys.argv[1], sys.argv[2]
+flags = sys.argv[3:]
+B.build()
+os.makedirs(os.path.join(ROOT, 'ab'), exist_ok=True)
+obj = os.path.join(ROOT, 'ab', f'{name}_{src[:-4]}.o')
+cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + B.EXTRA_FLAGS.get(src, []) + flags + ['-c', os.path.join(B.CSRC, src), '-o', obj]
+subprocess.check_call(cmd)
+objs = [os.path.join(B.CSRC, 'build', os.path.basename(s)[:-4] + '.o') for s in B.sources() if os.path.basename(s) != src] + [obj]
+out = os.path.join(ROOT, 'ab', f'lib{name}.so')
+subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+print(out)

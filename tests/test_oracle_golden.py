@@ -103,6 +103,26 @@ def test_vq(gold, rs_out):
     np.testing.assert_array_equal(idx1.numpy(), gold['vq.indices_T1'])
 
 
+def test_denormalise_pinned_to_the_reference_tail():
+    """oracle.denormalise against what the reference's OWN statements (modeling_internvl_chat.py:602-640, compiled out of
+    calli_align at generation time by scripts/make_golden_tail.py) produced: plain, drop_zero, hard VQ (incl. the
+    cos == 0.5 boundary), both, a single tile; mu/sigma in fp32 and in bf16 (result dtype follows the promotion)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_tail', os.path.join(ROOT, 'scripts', 'make_golden_tail.py'))
+    mgt = importlib.util.module_from_spec(spec)
+    sys.modules.setdefault('make_golden', type(sys)('make_golden'))       # the generator imports its sibling for paths only
+    sys.modules['make_golden'].install_stubs = lambda: None
+    sys.modules['make_golden'].OUT = GOLD
+    spec.loader.exec_module(mgt)
+    gold = np.load(os.path.join(GOLD, 'tail_vectors.npz'))
+    for name, seed, tiles, vocab, pdt, drop_zero, hard_vq in mgt.CASES:
+        table, mu, sigma, x, idx, cos = mgt.make_case(seed, tiles, vocab, pdt, drop_zero, hard_vq)
+        out, indices = calli_align.denormalise(x, idx, table, mu, sigma, drop_zero=drop_zero, hard_vq=hard_vq, cos=cos if hard_vq else None)
+        assert str(out.dtype) == bytes(gold[f'{name}.out_dtype']).decode(), name
+        np.testing.assert_array_equal(out.float().numpy(), gold[f'{name}.out'], err_msg=name)
+        np.testing.assert_array_equal(indices.numpy(), gold[f'{name}.indices'], err_msg=name)
+
+
 def test_denormalise_branches():
     # No importable reference function exists for the calli_align tail (it is inline at
     # modeling_internvl_chat.py:602-640), so this checks the restatement against the
