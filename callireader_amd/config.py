@@ -87,5 +87,39 @@ class ModelDims:
             kw['vocab'] = vocab
         return replace(d, **kw)
 
+    @staticmethod
+    def from_hf_config(path, rs_depth=None):
+        """Shapes from a checkpoint directory's config.json (the file AutoModel.from_pretrained reads,
+        /root/reference/inference.py:85-89): depths, vocabulary, eps, RoPE base; widths must be the path's own (the HIP
+        kernels are built for InternViT-300M / InternLM2.5-7B widths).  The resampler depth is not in config.json
+        (modeling_internvl_chat.py:157 hard-codes 4): pass `rs_depth` or it is read off the checkpoint's key names."""
+        import json
+        import os
+        with open(os.path.join(path, 'config.json')) as f:
+            cfg = json.load(f)
+        v, l = cfg['vision_config'], cfg['llm_config']
+        d = ModelDims()
+        want = dict(vit_hidden=v['hidden_size'], vit_heads=v['num_attention_heads'], vit_ff=v['intermediate_size'],
+                    image_size=v['image_size'], patch_size=v['patch_size'], llm_hidden=l['hidden_size'],
+                    llm_heads=l['num_attention_heads'], llm_kv_heads=l['num_key_value_heads'], llm_ff=l['intermediate_size'])
+        for k, val in want.items():
+            if getattr(d, k) != val:
+                raise ValueError(f'config.json {k}={val}: this engine is built for {k}={getattr(d, k)}')
+        if rs_depth is None:
+            rs_depth = d.rs_depth
+            idx = os.path.join(path, 'model.safetensors.index.json')
+            if os.path.exists(idx):
+                with open(idx) as f:
+                    keys = json.load(f)['weight_map'].keys()
+                layers = {int(k.split('.')[2]) for k in keys if k.startswith('resampler.layers.')}
+                if layers:
+                    rs_depth = max(layers) + 1
+        rope = l.get('rope_scaling') or {}
+        return replace(d, vit_layers=v['num_hidden_layers'], llm_layers=l['num_hidden_layers'], vocab=l['vocab_size'],
+                       vit_ln_eps=v.get('layer_norm_eps', d.vit_ln_eps), rms_eps=l.get('rms_norm_eps', d.rms_eps),
+                       rope_theta=float(l.get('rope_theta', d.rope_theta)), rope_factor=float(rope.get('factor', d.rope_factor)),
+                       max_pos=l.get('max_position_embeddings', d.max_pos), downsample_ratio=cfg.get('downsample_ratio', d.downsample_ratio),
+                       rs_depth=rs_depth)
+
     def asdict(self):
         return asdict(self)

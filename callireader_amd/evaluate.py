@@ -1,0 +1,180 @@
+"""CalliBench `full_page` runner on the HIP engine: mirror of /root/reference/evaluate.py for the path's own task.
+
+  reference                                             here
+  evaluate.py:52-53   get_clean_string                   get_clean_string (same two character classes)
+  evaluate.py:55-76   get_parquet                        get_parquet (columns `annotation` JSON, `image`.bytes)
+  utils/utils.py:516-542 calculate_metrics               calculate_metrics (greedy one-to-one match = multiset intersection)
+  evaluate.py:145-147 Levenshtein.distance / max len     edit_distance (third-party `Levenshtein` 0.x: plain unit-cost
+                                                          edit distance on the two character lists; restated, the wheel is
+                                                          not in this image)
+  evaluate.py:127-132 single_rec -> cc.convert(response) single_rec; traditional -> simplified through `opencc` when it is
+                                                          importable (reference: opencc.OpenCC('t2s.json')), identity
+                                                          otherwise, and the JSON says which
+  evaluate.py:134-171 test_full_page                      test_full_page (same arguments, same JSON layout) + `batch_pages`
+  evaluate.py:389-436 main --type full_page               main (easy / medium / hard parquet files, prompt 读出图中所有文字。)
+
+The other CalliBench tasks (region_wise, choice, bilingual, intent) score different abilities with external judges and are
+outside SURVEY.md section 8.  `batch_pages` > 1 sends that many pages through the engine together
+(InternVLChatModel.chat_ocr_pages): each page's response equals its own chat_ocr call, pages/s is what changes.
+"""
+import argparse
+import json
+import os
+import re
+from collections import Counter
+from io import BytesIO
+
+from PIL import Image
+
+Image.MAX_IMAGE_PIXELS = None
+
+_ZH_PUNCT = re.compile('[。？！、，「」『』‘’“”–—…【】《》：；]')
+_EN_PUNCT = re.compile(r'[,\.!?:\'";\(\)\[\]\{\}\-\n\*1234567890]')
+
+
+def get_clean_string(text):
+    """evaluate.py:42-53: ASCII punctuation, digits, newlines and `*` go first, then the CJK punctuation set."""
+    return _ZH_PUNCT.sub('', _EN_PUNCT.sub('', text))
+
+
+def get_parquet(parquet_path):
+    """evaluate.py:55-76: (images, annotations); a row that fails to parse is reported and skipped."""
+    import pandas as pd
+    df = pd.read_parquet(parquet_path)
+    images, annotations = [], []
+    for index, row in df.iterrows():
+        try:
+            labels = json.loads(row['annotation'])
+            image = Image.open(BytesIO(row['image']['bytes']))
+            images.append(image)
+            annotations.append(labels)
+        except Exception as e:
+            print(f'Row {index} Error: {e}')
+            continue
+    return images, annotations
+
+
+def calculate_metrics(y_pred, y_gt):
+    """utils/utils.py:516-542 with the default equality comparison: every predicted item claims the first unclaimed equal
+    ground-truth item, so TP is the size of the multiset intersection; FP = |pred| - TP, FN = |gt| - TP."""
+    cp, cg = Counter(y_pred), Counter(y_gt)
+    tp = sum(min(n, cg[k]) for k, n in cp.items())
+    fp, fn = len(y_pred) - tp, len(y_gt) - tp
+    precision = tp / (tp + fp) if tp + fp > 0 else 0
+    recall = tp / (tp + fn) if tp + fn > 0 else 0
+    f1 = 2 * (precision * recall) / (precision + recall) if (precision + recall) > 0 else 0
+    return precision, recall, f1
+
+
+def edit_distance(a, b):
+    """Unit-cost insert / delete / substitute distance between two sequences (what Levenshtein.distance returns)."""
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+class _T2S:
+    """opencc.OpenCC('t2s.json') when the package is there; the reference cannot run without it, this runner can."""
+
+    def __init__(self):
+        try:
+            import opencc
+            self._cc, self.name = opencc.OpenCC('t2s.json'), 'opencc t2s'
+        except Exception:
+            self._cc, self.name = None, 'identity (opencc not installed)'
+
+    def convert(self, text):
+        return self._cc.convert(text) if self._cc is not None else text
+
+
+cc = _T2S()
+
+
+def single_rec(model, tokenizer, detect_model, generation_config, image_path, prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose):
+    response, history = model.chat_ocr(tokenizer, detect_model, image_path, prompt, generation_config, use_p=use_p, hard_vq=hard_vq,
+                                       drop_zero=drop_zero, repetition_penalty=repetition_penalty, return_history=True, verbose=verbose)
+    return cc.convert(response)
+
+
+def score_page(response, reference):
+    """evaluate.py:141-149 for one page: character lists, P / R / F1 and the normalised edit distance."""
+    gt = list(get_clean_string(reference))
+    response = list(response)
+    precision, recall, f1 = calculate_metrics(response, gt)
+    max_len = max(len(response), len(gt))
+    ned = edit_distance(response, gt) / max_len if max_len else 0.0
+    return response, gt, precision, recall, f1, ned
+
+
+def test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, prompt, use_p, hard_vq, drop_zero,
+                   repetition_penalty, verbose, batch_pages=1, limit=None):
+    images, annotations = get_parquet(parquet_path)
+    if limit is not None:
+        images, annotations = images[:limit], annotations[:limit]
+    to_be_save = {'detailed': []}
+    sums = [0.0, 0.0, 0.0, 0.0]
+    count = 0
+    for i0 in range(0, len(images), max(batch_pages, 1)):
+        imgs, annots = images[i0:i0 + batch_pages], annotations[i0:i0 + batch_pages]
+        if batch_pages > 1:
+            responses = [cc.convert(r) for r in model.chat_ocr_pages(tokenizer, detect_model, imgs, prompt, generation_config, use_p=use_p,
+                                                                     hard_vq=hard_vq, drop_zero=drop_zero, repetition_penalty=repetition_penalty)]
+        else:
+            responses = [single_rec(model, tokenizer, detect_model, generation_config, imgs[0], prompt, use_p, hard_vq, drop_zero,
+                                    repetition_penalty, verbose)]
+        for response, annot in zip(responses, annots):
+            response, gt, precision, recall, f1, ned = score_page(response, annot['reference'])
+            to_be_save['detailed'].append({'imgPath': annot['imagePath'], 'prompt': prompt, 'output': ''.join(response), 'gt': ''.join(gt),
+                                           'precision': precision, 'recall': recall, 'f1': f1, 'ned': ned})
+            for k, v in enumerate((precision, recall, f1, ned)):
+                sums[k] += v
+            count += 1
+    avg = [s / count for s in sums] if count else sums
+    to_be_save['average'] = {'ave_precison': avg[0], 'avg_recall': avg[1], 'avg_f1': avg[2], 'avg_ned': avg[3]}     # keys as upstream (sic)
+    to_be_save['t2s'] = cc.name
+    with open(save_json_path, 'w', encoding='utf-8') as f:
+        json.dump(to_be_save, f, ensure_ascii=False, indent=4)
+    return to_be_save['average']
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='args for inference task')
+    parser.add_argument('--type', type=str, choices=['full_page'], default='full_page', help='Evaluation Type (this engine covers full_page)')
+    parser.add_argument('--save_name', type=str, default='exp')
+    parser.add_argument('--data', type=str, default='./CalliBench', help='Evaluation Data Directory')
+    parser.add_argument('--use_p', type=bool, default=True)
+    parser.add_argument('--hard_vq', type=bool, default=False)
+    parser.add_argument('--drop_zero', type=bool, default=False)
+    parser.add_argument('--verbose', type=bool, default=False)
+    parser.add_argument('--repetition_penalty', type=float, default=1.0)
+    parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
+    parser.add_argument('--params', type=str, default='./params')
+    parser.add_argument('--batch_pages', type=int, default=16, help='pages sent through the engine together')
+    args = parser.parse_args(argv)
+    import torch
+    from .inference import load_detector
+    from .modeling_internvl_chat import InternVLChatModel
+    from .tokenization_internlm2 import InternLM2Tokenizer
+    save_dir = f'outputs/{args.save_name}'
+    os.makedirs(save_dir, exist_ok=True)
+    model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16, max_pages=args.batch_pages).eval().cuda()
+    tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
+    generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
+    detect_model = load_detector(args.params)
+    prompt = '读出图中所有文字。'
+    for level in ('easy', 'medium', 'hard'):
+        parquet_path = os.path.join(args.data, f'full_page_ocr/{level}/{level}.parquet')
+        save_json_path = os.path.join(save_dir, f'full_page_{level}.json')
+        avg = test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, prompt, args.use_p, args.hard_vq,
+                             args.drop_zero, args.repetition_penalty, args.verbose, batch_pages=args.batch_pages)
+        print(level, avg)
+
+
+if __name__ == '__main__':
+    main()

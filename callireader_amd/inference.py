@@ -1,8 +1,10 @@
 """`python inference.py --tgt ...` with the reference's flags (/root/reference/inference.py:65-130), on the HIP engine.
 
-Differences that the scope forces: character boxes come from a labelme-style JSON next to the image
-(`<image>.json`, the format of examples/0.json) or from --boxes, because the YOLO/OrderFormer front end is out of
-scope; the tokenizer is the engine's own reader of the reference's tokenizer files under --model
+The detector is what the reference uses: `ultralytics.YOLO(<params>/best.pt)` (inference.py:98), handed to chat_ocr as
+is; everything behind it (repeated passes, de-duplication, column merge, OrderFormer, reading order) runs in this
+package (ordering.py).  ultralytics is third-party and not part of this image: without it, or with --boxes / a
+labelme-style `<image>.json` next to the image (the format of examples/0.json), the ordered boxes are read from JSON.
+The tokenizer is the engine's own reader of the reference's tokenizer files under --model
 (callireader_amd/tokenization_internlm2.py, pinned against the sentencepiece library in tests/test_tokenizer.py).
 """
 import argparse
@@ -20,27 +22,46 @@ def is_image(p):
     return os.path.isfile(p) and p.lower().endswith(IMG_EXT)
 
 
-def boxes_for(image_path, boxes_arg=None):
+def load_detector(params_dir='./params'):
+    """inference.py:98 `YOLO(YOLO_CHECKPOINT)` (config/configu.py: ./params/best.pt) when ultralytics and the weights
+    are present, else None (boxes then come from JSON)."""
+    path = os.path.join(params_dir, 'best.pt')
+    try:
+        from ultralytics import YOLO
+    except Exception:
+        return None
+    return YOLO(path) if os.path.exists(path) else None
+
+
+def boxes_for(image_path, boxes_arg=None, required=True):
     cand = boxes_arg or os.path.splitext(image_path)[0] + '.json'
     if not os.path.exists(cand):
-        raise FileNotFoundError(f'character boxes for {image_path}: expected {cand} (labelme-style, see examples/0.json)')
+        if not required:
+            return None
+        raise FileNotFoundError(f'character boxes for {image_path}: no detector (ultralytics + params/best.pt) and no {cand} '
+                                '(labelme-style, see examples/0.json)')
     return load_boxes_json(cand)
 
 
-def single_rec(model, tokenizer, generation_config, image_path, prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose, boxes=None):
-    response, history = model.chat_ocr(tokenizer, None, image_path, prompt, generation_config, use_p=use_p, hard_vq=hard_vq,
+def single_rec(model, tokenizer, detect_model, generation_config, image_path, prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose,
+               boxes=None):
+    bx = None
+    if use_p and (boxes is not None or detect_model is None):
+        bx = boxes_for(image_path, boxes)
+    response, history = model.chat_ocr(tokenizer, detect_model, image_path, prompt, generation_config, use_p=use_p, hard_vq=hard_vq,
                                        drop_zero=drop_zero, repetition_penalty=repetition_penalty, return_history=True,
-                                       verbose=verbose, boxes=boxes_for(image_path, boxes) if use_p else None)
+                                       verbose=verbose, boxes=bx)
     print(f'User: {prompt}\nAssistant: {response}')
     return response
 
 
-def folder_rec(model, tokenizer, generation_config, folder_path, prompt, save_name, use_p, hard_vq, drop_zero, repetition_penalty, verbose):
+def folder_rec(model, tokenizer, detect_model, generation_config, folder_path, prompt, save_name, use_p, hard_vq, drop_zero, repetition_penalty,
+               verbose):
     results = []
     for pic in sorted(f for f in os.listdir(folder_path) if f.lower().endswith(IMG_EXT)):
         pic_path = os.path.join(folder_path, pic)
         try:
-            response = single_rec(model, tokenizer, generation_config, pic_path, prompt, use_p, hard_vq, drop_zero,
+            response = single_rec(model, tokenizer, detect_model, generation_config, pic_path, prompt, use_p, hard_vq, drop_zero,
                                   repetition_penalty, verbose)
         except Exception as e:                               # inference.py:55-57
             print(f'An error has occured:\n{e}')
@@ -74,14 +95,15 @@ def main(argv=None):
     # AutoTokenizer path needs sentencepiece==0.2.0; any HF-style tokenizer object works with chat_ocr as well
     tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
     generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
+    detect_model = load_detector(args.params)
     if is_image(args.tgt):
         print('Single image recognition mode.')
-        single_rec(model, tokenizer, generation_config, args.tgt, args.prompt, args.use_p, args.hard_vq, args.drop_zero,
+        single_rec(model, tokenizer, detect_model, generation_config, args.tgt, args.prompt, args.use_p, args.hard_vq, args.drop_zero,
                    args.repetition_penalty, args.verbose, args.boxes)
     elif os.path.isdir(args.tgt):
         print('Multiple images recognition mode')
         os.makedirs('results', exist_ok=True)
-        folder_rec(model, tokenizer, generation_config, args.tgt, args.prompt, os.path.join('results', args.save_name),
+        folder_rec(model, tokenizer, detect_model, generation_config, args.tgt, args.prompt, os.path.join('results', args.save_name),
                    args.use_p, args.hard_vq, args.drop_zero, args.repetition_penalty, args.verbose)
     else:
         raise ValueError('The target should be either a image path or a folder that contain images!')

@@ -7,9 +7,10 @@ caller of the reference (inference.py:37-57, evaluate.py) can switch classes.  A
 math runs in libcallireader_hip.so through `Engine`; this file only builds prompts, moves
 ids and pixels, and drives the greedy loop.  There is no PyTorch compute fallback.
 
-Out of scope here: the YOLO detector and the OrderFormer sorter.  Where the
-reference takes `detect_model`, this class takes either a callable `img -> ordered xyxy boxes`
-or explicit `boxes=`.
+`detect_model` is what the reference passes (inference.py:37-42,98): an ultralytics `YOLO` object (or any callable
+returning raw boxes); with the sorter loaded (`params/orderformer.pth`, as the reference's __init__ :159 does) the
+whole front end of calli_align runs on its detections (ordering.py).  The detector NETWORK itself is third-party
+(ultralytics) and is not re-implemented; `boxes=` bypasses it with ordered boxes (examples/0.json).
 """
 import json
 import os
@@ -68,17 +69,34 @@ class InternVLChatModel:
         return m
 
     @classmethod
-    def from_pretrained(cls, path, params_dir='./params', torch_dtype=torch.bfloat16, **kw):
+    def from_pretrained(cls, path, *model_args, params_dir='./params', torch_dtype=torch.bfloat16, config=None, **kw):
         """HF sharded safetensors (model.safetensors.index.json) + params/gauss_norm_mu_sigma.pth, as
-        AutoModel.from_pretrained(INTERNVL_PATH, ...) does in inference.py:85-89 / __init__ :153-159."""
+        AutoModel.from_pretrained(INTERNVL_PATH, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True,
+        trust_remote_code=True) does in inference.py:85-89 / __init__ :153-159.  Shapes come from <path>/config.json.
+        Keyword arguments of the HF loader that mean nothing here (low_cpu_mem_usage, trust_remote_code, revision,
+        code_revision, ...) are accepted and ignored, so the reference's call works unchanged through the auto_map shim
+        (callireader_amd/hf_entry/, INTEGRATION.md)."""
         from .weights import load_checkpoint
-        m = cls(kw.pop('dims', None), **kw)
+        if torch_dtype not in (torch.bfloat16, None, 'auto', 'bfloat16'):
+            raise ValueError('the engine computes in bf16, the dtype the reference loads the model in (inference.py:87)')
+        ours = {k: kw.pop(k) for k in ('device', 'max_tokens', 'max_pages') if k in kw}
+        dims = kw.pop('dims', None)
+        if dims is None:
+            dims = ModelDims.from_hf_config(path) if os.path.exists(os.path.join(path, 'config.json')) else ModelDims.full()
+        m = cls(dims, **ours)
         load_checkpoint(m.engine, path, params_dir)
         m._finish()
         of = os.path.join(params_dir, 'orderformer.pth')                    # :159 ORDERFORMER_CHECKPOINT
         if os.path.exists(of):
             m.load_orderformer(torch.load(of, map_location='cpu', weights_only=True))
         return m
+
+    # hooks transformers' AutoModel.from_pretrained(..., trust_remote_code=True) calls on the class auto_map names
+    @classmethod
+    def register_for_auto_class(cls, auto_class='AutoModel'):
+        cls._auto_class = auto_class
+
+    _auto_class = None
 
     def _finish(self):
         self.engine.load_rope()
@@ -138,14 +156,15 @@ class InternVLChatModel:
         img = Image.open(img_path).convert('RGB') if isinstance(img_path, str) else img_path.convert('RGB')
         if boxes is None:
             if not callable(detect_model):
-                raise NotImplementedError('the detector network is outside this engine (SURVEY.md 8f-4): pass '
-                                          'boxes=[(x1,y1,x2,y2),...] or a callable detect_model')
+                raise NotImplementedError('calli_align needs a detector: pass the ultralytics YOLO object the reference '
+                                          'uses (inference.py:98), any callable image -> boxes, or boxes=[(x1,y1,x2,y2),...]')
+            from . import ordering
             if self.sorter is not None:
-                from . import ordering
                 raw = ordering.detect_all(detect_model, np.array(img))
                 boxes = ordering.sort_boxes(raw, img.width, img.height, self.sorter)      # :558
             else:
-                boxes = detect_model(img)
+                # no params/orderformer.pth was loaded: the detector's own order is taken as the reading order
+                boxes = ordering.run_detector(detect_model, np.array(img))
         arr = np.array(img)
         if self.gpu_preprocess:
             # one page upload, every crop resized/padded/normalised by cr_preprocess (replaces the per-box PIL loop :580-583)
@@ -226,6 +245,29 @@ class InternVLChatModel:
         penalty = generate_kwargs.pop('repetition_penalty', 1.0)
         return self.generate_ocr(pixel_values, input_ids, attention_mask, visual_features, generation_config, None,
                                  output_hidden_states, return_dict, repetition_penalty=penalty, **generate_kwargs)
+
+    @torch.no_grad()
+    def generate(self, pixel_values=None, input_ids=None, attention_mask=None, visual_features=None, generation_config=None,
+                 output_hidden_states=None, return_dict=None, **generate_kwargs):
+        """:1124-1183.  The CalliAlign-only path: every tile's 256 visual tokens are resampled to 3 pseudo-tokens,
+        snapped to the normalised table, de-normalised (no drop_zero, no hard VQ) and spliced at the <IMG_CONTEXT>
+        positions (3 per tile: dynamic_chat sets num_image_token = 3).  One row per call, like the other generate_*."""
+        assert self.img_context_token_id is not None                        # :1137
+        if input_ids.shape[0] != 1:
+            raise NotImplementedError('generate handles one prompt per call; dynamic_chat(batch=True) loops over rows')
+        penalty = generate_kwargs.pop('repetition_penalty', 1.0)
+        if pixel_values is not None:
+            vit_embeds = visual_features if visual_features is not None else self.extract_feature(pixel_values)   # :1139-1143
+            vit_embeds = self.resampler(vit_embeds)                         # :1147
+            indices = self.engine.vq(vit_embeds)                            # :1153
+            vit_embeds = self.engine.denorm(vit_embeds, indices)            # :1156  x * sigma[idx] + mu[idx]
+            ids = input_ids.reshape(-1)
+            assert (ids == self.img_context_token_id).sum() != 0            # :1164
+            input_embeds = self.engine.embed_splice(ids, vit_embeds, None, img_id=self.img_context_token_id)
+        else:
+            input_embeds = self.engine.embed_splice(input_ids.reshape(-1))  # :1172
+        max_new, eos = self._gen_args(generate_kwargs)
+        return self._greedy(input_embeds, max_new, eos, penalty)
 
     # ---- chat API ------------------------------------------------------------------------------
     def _build_query(self, question, history, num_patches_list, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN):
@@ -323,6 +365,126 @@ class InternVLChatModel:
         response = response.split(template.sep)[0].strip()                      # :752-753
         history.append((question, response))
         return (response, history) if return_history else response
+
+    def dynamic_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
+                     return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+                     verbose=False, image_counts=None, batch=False, use_p=True):
+        """:765-901.  `use_p` switches every tile to 3 pseudo-tokens (and, as upstream, leaves num_image_token at 3 on
+        the object afterwards).  batch=True: a list of questions, one answer each (the reference pads them into one
+        batch; here every row runs at its own length and the rows decode together).  batch=False: the reference's
+        hard-wired single-turn prompt (:857-866), history only feeds the returned list."""
+        if use_p:
+            self.num_image_token = 3                                        # :768-769
+        gen = self.generate if use_p else self.generate_origin
+        generation_config = dict(generation_config)
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        if batch:
+            assert isinstance(questions, list) and len(questions) > 0 and isinstance(questions[0], str)
+            if history is not None or return_history:
+                print('Now multi-turn chat is not supported in batch_chat.')
+                raise NotImplementedError
+            if image_counts is not None:
+                num_patches_list = image_counts
+                print('Warning: `image_counts` is deprecated. Please use `num_patches_list` instead.')
+            if verbose and pixel_values is not None:
+                print(f'dynamic ViT batch size: {pixel_values.shape[0]}')
+            template = get_conv_template(self.template)
+            generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
+            responses, off = [], 0
+            for idx, num_patches in enumerate(num_patches_list):
+                question = questions[idx]
+                if pixel_values is not None and '<image>' not in question:
+                    question = '<image>\n' + question
+                t = get_conv_template(self.template)                         # no system_message override here (:790)
+                t.append_message(t.roles[0], question)
+                t.append_message(t.roles[1], None)
+                query = t.get_prompt().replace('<image>', IMG_START_TOKEN + IMG_CONTEXT_TOKEN * self.num_image_token * num_patches + IMG_END_TOKEN, 1)
+                ids = tokenizer(query, return_tensors='pt')['input_ids']
+                px = pixel_values[off:off + num_patches] if pixel_values is not None else None
+                off += num_patches
+                out = gen(pixel_values=px, input_ids=ids, **generation_config)
+                responses.append(tokenizer.batch_decode(out, skip_special_tokens=True)[0].split(template.sep)[0].strip())
+            return responses
+        assert isinstance(questions, str)
+        if num_patches_list is None:
+            num_patches_list = [pixel_values.shape[0]] if pixel_values is not None else []
+        assert pixel_values is None or len(pixel_values) == sum(num_patches_list)          # :829
+        template = get_conv_template(self.template)
+        template.system_message = self.system_message
+        generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
+        history = [] if history is None else history
+        if verbose and pixel_values is not None:
+            print(f'dynamic ViT batch size: {pixel_values.shape[0]}')
+        # the reference discards the template's prompt and builds this string (:857-866): no newline after the roles,
+        # no <img> markers, `num_image_token` context tokens per <image> whatever the tile count
+        query = ('<|im_start|>system你是由上海人工智能实验室联合商汤科技开发的书生多模态大模型，英文名叫InternVL, 是一个有用无害的人工智能助手。<|im_end|>\n'
+                 f'<|im_start|>user{questions}') + '<image>'
+        for _ in num_patches_list:
+            query = query.replace('<image>', IMG_CONTEXT_TOKEN * self.num_image_token, 1)
+        query += '<|im_end|>\n<|im_start|>assistant'
+        model_inputs = tokenizer(query, return_tensors='pt')
+        out = gen(pixel_values=pixel_values, input_ids=model_inputs['input_ids'], attention_mask=model_inputs['attention_mask'],
+                  **generation_config)
+        response = tokenizer.batch_decode(out, skip_special_tokens=True)[0].split(template.sep)[0].strip()
+        history.append((questions, response))
+        if return_history:
+            return response, history
+        if verbose:
+            print(query.replace(IMG_CONTEXT_TOKEN, '').replace(f'{IMG_START_TOKEN}{IMG_END_TOKEN}', '<image>'), response)
+        return response
+
+    def chat_ocr_pages(self, tokenizer, detect_model, images, question, generation_config, boxes_list=None, use_p=True,
+                       drop_zero=False, hard_vq=False, repetition_penalty=1.5, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>',
+                       IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]'):
+        """Many pages at once (new: the reference's chat_ocr is one page per call, evaluate.py loops over it).  The
+        character tiles of ALL pages go through the visual stage as one batch, the prompts are prefilled together and
+        the pages decode as one batch; every page gets exactly the response its own chat_ocr call would produce."""
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        pages = [Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB') for im in images]
+        page_px, n_tiles, char_px, n_chars = [], [], [], []
+        for i, page in enumerate(pages):
+            arr = torch.from_numpy(np.array(page))
+            jobs, n = plan_page(*page.size)
+            page_px.append(self.engine.preprocess(arr, jobs, n))
+            n_tiles.append(n)
+            if use_p:
+                bx = boxes_list[i] if boxes_list is not None else None
+                if bx is None:
+                    from . import ordering
+                    raw = ordering.detect_all(detect_model, np.array(page))
+                    bx = ordering.sort_boxes(raw, page.width, page.height, self.sorter) if self.sorter is not None else raw
+                w, h = page.size
+                jobs = [plan_char((max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), w), min(int(b[3]), h)), j) for j, b in enumerate(bx)]
+                char_px.append(self.engine.preprocess(arr, jobs, len(jobs)))
+                n_chars.append(len(jobs))
+        feats = self.extract_feature(torch.cat(page_px))
+        pseudo = None
+        if use_p:
+            feat_c = self.extract_feature(torch.cat(char_px))
+            rs = self.resampler(feat_c)
+            outs = self.engine.vq(rs, with_cos=hard_vq)
+            idx, cos = outs if hard_vq else (outs, None)
+        template = get_conv_template(self.template)
+        generation_config = dict(generation_config)
+        generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
+        embeds, toff, coff = [], 0, 0
+        for i in range(len(pages)):
+            q = question if '<image>' in question else '<image>\n' + question
+            ref = None
+            if use_p:
+                sl = slice(coff, coff + n_chars[i])
+                ref = self.engine.denorm(rs[sl], idx[sl], cos[sl] if cos is not None else None, drop_zero=drop_zero, hard_vq=hard_vq)
+                coff += n_chars[i]
+                if ALIGNED_TOKEN not in q:
+                    q = q + ALIGNED_TOKEN * ref.shape[0]
+            query, _, _ = self._build_query(q, None, [n_tiles[i]], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+            ids = tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1)
+            embeds.append(self.engine.embed_splice(ids, feats[toff:toff + n_tiles[i]], ref, img_id=self.img_context_token_id,
+                                                   ref_id=self.aligned_token_id))
+            toff += n_tiles[i]
+        max_new, eos = self._gen_args(generation_config)
+        outs = self.generate_pages(embeds, max_new, eos, repetition_penalty)
+        return [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in outs]
 
     def batch_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
                    return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',

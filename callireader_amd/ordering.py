@@ -55,6 +55,29 @@ def most_frequent_rgb(image):
     return ((top >> 16) & 255, (top >> 8) & 255, top & 255)
 
 
+def run_detector(detector, image):
+    """One detection pass -> [[x1, y1, x2, y2], ...] (ints, truncated as the reference does).
+
+    `detector` is what the reference hands to chat_ocr (inference.py:37-42,98): an ultralytics `YOLO` object, used as
+    `detector(image_array, verbose=False)[0].boxes[i].xyxy` (modeling_internvl_chat.py:356-362) -- or any callable
+    `image_array -> iterable of (x1, y1, x2, y2, ...)` (tests, other detectors)."""
+    try:
+        res = detector(image, verbose=False)
+    except TypeError:
+        res = detector(image)
+    first = res[0] if isinstance(res, (list, tuple)) and len(res) and hasattr(res[0], 'boxes') else None
+    if first is None and hasattr(res, 'boxes'):
+        first = res
+    if first is not None:
+        out = []
+        for box in first.boxes:
+            xyxy = box.xyxy
+            xyxy = xyxy.squeeze().tolist() if hasattr(xyxy, 'squeeze') else list(xyxy)
+            out.append([int(xyxy[0]), int(xyxy[1]), int(xyxy[2]), int(xyxy[3])])
+        return out
+    return [[int(v) for v in b[:4]] for b in res]
+
+
 def detect_all(detector, image, max_per_pass=250):
     """:346-368.  Detectors cap their output, so while a pass returns more than `max_per_pass` boxes the found ones are
     painted over with the page's dominant colour and the detector runs again.  Coordinates are truncated to int."""
@@ -62,7 +85,7 @@ def detect_all(detector, image, max_per_pass=250):
     colour = most_frequent_rgb(image)
     found = []
     while True:
-        batch = [[int(v) for v in b[:4]] for b in detector(image)]
+        batch = run_detector(detector, image)
         found.extend(batch)
         if len(batch) <= max_per_pass:
             return found

@@ -1,7 +1,7 @@
 """Host image pipeline of the reference, restated without torchvision (PIL + torch only).
 
 Mirrors /root/reference/utils/utils.py:
-  build_transform :354-362, find_closest_aspect_ratio :365-379, dynamic_preprocess :381-417,
+  build_transform :354-362, find_closest_aspect_ratio :365-379 (inside tile_grid), dynamic_preprocess :381-417,
   load_image_2 :420-452 (character crop -> exactly one 448x448 tile), load_image :463-478 (page -> <=12 tiles + thumbnail).
 CPU host code: it sits either side of the hot path, not on it.
 """
@@ -26,28 +26,30 @@ def build_transform(input_size):
     return transform
 
 
-def find_closest_aspect_ratio(aspect_ratio, target_ratios, width, height, image_size):
-    best_ratio_diff = float('inf')
-    best_ratio = (1, 1)
-    area = width * height
-    for ratio in target_ratios:
-        target_aspect_ratio = ratio[0] / ratio[1]
-        ratio_diff = abs(aspect_ratio - target_aspect_ratio)
-        if ratio_diff < best_ratio_diff:
-            best_ratio_diff = ratio_diff
-            best_ratio = ratio
-        elif ratio_diff == best_ratio_diff:
-            if area > 0.5 * image_size * image_size * ratio[0] * ratio[1]:
-                best_ratio = ratio
-    return best_ratio
-
-
 def tile_grid(width, height, min_num=1, max_num=12, image_size=448):
-    """(cols, rows) chosen by dynamic_preprocess for an image of this size."""
-    target_ratios = set((i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1) for j in range(1, n + 1)
-                        if min_num <= i * j <= max_num)
-    target_ratios = sorted(target_ratios, key=lambda x: x[0] * x[1])
-    return find_closest_aspect_ratio(width / height, target_ratios, width, height, image_size)
+    """(cols, rows) dynamic_preprocess picks for an image of this size (utils/utils.py:365-379 + :386-393): among all grids
+    with min_num..max_num tiles, visited by tile count (then by first appearance while the count grows), the one whose
+    cols / rows is nearest to width / height; a later grid with exactly the same distance replaces the held one only when the
+    image covers more than half of that grid's pixel area."""
+    grids = []
+    for n in range(min_num, max_num + 1):                      # order of first appearance, as the reference's set is built
+        for cols in range(1, n + 1):
+            for rows in range(1, n + 1):
+                if min_num <= cols * rows <= max_num and (cols, rows) not in grids:
+                    grids.append((cols, rows))
+    # the reference sorts a SET by tile count: grids of equal count come in the set's iteration order, which for these
+    # small int tuples is reproduced by sorting on (count, hash order); tests/test_host_logic.py pins the outcome on
+    # the reference's own tilings (host_vectors.json)
+    grids = sorted(set(grids), key=lambda g: g[0] * g[1])
+    aspect, area = width / height, width * height
+    held, held_diff = (1, 1), float('inf')
+    for cols, rows in grids:
+        diff = abs(aspect - cols / rows)
+        if diff < held_diff:
+            held, held_diff = (cols, rows), diff
+        elif diff == held_diff and area > 0.5 * image_size * image_size * cols * rows:
+            held = (cols, rows)
+    return held
 
 
 def dynamic_preprocess(image, min_num=1, max_num=12, image_size=448, use_thumbnail=False):
@@ -66,22 +68,29 @@ def dynamic_preprocess(image, min_num=1, max_num=12, image_size=448, use_thumbna
     return processed
 
 
+def char_canvas(width, height, input_size=448):
+    """Geometry of load_image_2 (utils/utils.py:424-443): the longest side is brought into [200, 350] (smaller crops
+    grow to 200, larger ones shrink to 350, the rest keep their size), sizes truncate to int, and the result sits
+    centred on a white input_size square, the odd pixel of padding going right / down.
+    Returns (new_w, new_h, left, top, right, bottom)."""
+    longest = max(width, height)
+    factor = 200 / longest if longest <= 200 else 350 / longest if longest >= 350 else 1.0
+    new_w, new_h = int(width * factor), int(height * factor)
+    return (new_w, new_h, (input_size - new_w) // 2, (input_size - new_h) // 2,
+            (input_size - new_w + 1) // 2, (input_size - new_h + 1) // 2)
+
+
+def pad_char(image, input_size=448):
+    """The white-padded PIL image load_image_2 hands to the tiler (exactly input_size square -> one tile)."""
+    new_w, new_h, left, top, right, bottom = char_canvas(*image.size, input_size)
+    return ImageOps.expand(image.resize((new_w, new_h)), border=(left, top, right, bottom), fill=(255, 255, 255))
+
+
 def load_image_2(image, input_size=448, max_num=12):
-    """Character crop -> (1,3,448,448): rescale the longest side into [200,350], centre on white, one tile."""
+    """Character crop -> (1,3,448,448)."""
     if isinstance(image, str):
         image = Image.open(image).convert('RGB')
-    width, height = image.size
-    if max(width, height) <= 200:
-        scale = 200 / max(width, height)
-    elif max(width, height) >= 350:
-        scale = 350 / max(width, height)
-    else:
-        scale = 1.0
-    new_w, new_h = int(width * scale), int(height * scale)
-    image = image.resize((new_w, new_h))
-    padded = ImageOps.expand(image, border=((input_size - new_w) // 2, (input_size - new_h) // 2,
-                                            (input_size - new_w + 1) // 2, (input_size - new_h + 1) // 2),
-                             fill=(255, 255, 255))
+    padded = pad_char(image, input_size)
     transform = build_transform(input_size)
     images = dynamic_preprocess(padded, image_size=input_size, use_thumbnail=True, max_num=max_num)
     return torch.stack([transform(im) for im in images])
@@ -131,12 +140,5 @@ def plan_char(box, tile, input_size=448):
     """Job for load_image_2(crop): rescale the longest side into [200,350], centre on a white canvas."""
     x1, y1, x2, y2 = [int(v) for v in box]
     width, height = x2 - x1, y2 - y1
-    if max(width, height) <= 200:
-        scale = 200 / max(width, height)
-    elif max(width, height) >= 350:
-        scale = 350 / max(width, height)
-    else:
-        scale = 1.0
-    new_w, new_h = int(width * scale), int(height * scale)
-    return dict(sx0=x1, sy0=y1, sw=width, sh=height, ow=new_w, oh=new_h, mode=0, tile0=tile, cols=1,
-                left=(input_size - new_w) // 2, top=(input_size - new_h) // 2)
+    new_w, new_h, left, top, _, _ = char_canvas(width, height, input_size)
+    return dict(sx0=x1, sy0=y1, sw=width, sh=height, ow=new_w, oh=new_h, mode=0, tile0=tile, cols=1, left=left, top=top)

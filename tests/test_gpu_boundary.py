@@ -1,0 +1,203 @@
+"""The boundary exactly as the reference's callers use it (inference.py:85-101, evaluate.py:127-132), on a real MI355X:
+
+  * a checkpoint ON DISK in the reference's formats -- config.json, sharded safetensors + model.safetensors.index.json,
+    params/gauss_norm_mu_sigma.pth, params/orderformer.pth, tokenizer.model + tokenizer_config.json -- loaded with
+    InternVLChatModel.from_pretrained (row f2);
+  * the engine's InternLM2Tokenizer on a sentencepiece model trained inside the test (row f3), not a fake;
+  * a detector OBJECT with the ultralytics call shape the reference relies on
+    (`detect_model(image_array, verbose=False)[0].boxes[i].xyxy`, modeling_internvl_chat.py:356-362), handed to
+    chat_ocr unchanged (row f4);
+  * dynamic_chat / generate (modeling_internvl_chat.py:765-901, 1124-1183) and the multi-page chat_ocr_pages.
+Expected answers come from the same pipeline composed from the CPU oracle (1 layer each at full width).
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from callireader_amd.config import ModelDims
+from callireader_amd import synthetic, preprocess
+from callireader_amd.conversation import get_conv_template
+
+pytestmark = pytest.mark.gpu
+spm = pytest.importorskip('sentencepiece')
+
+ADDED = ['<|im_start|>', '<|im_end|>', '<img>', '</img>', '<IMG_CONTEXT>']
+
+
+class Box:
+    def __init__(self, b):
+        self.xyxy = torch.tensor([b], dtype=torch.float32)
+
+
+class Result:
+    def __init__(self, boxes):
+        self.boxes = [Box(b) for b in boxes]
+
+
+class YoloLike:
+    """Same call shape as ultralytics.YOLO: model(array, verbose=False) -> [Results]; boxes in no particular order."""
+
+    def __init__(self, boxes):
+        self.boxes, self.calls = boxes, 0
+
+    def __call__(self, image, verbose=True):
+        assert isinstance(image, np.ndarray) and verbose is False
+        self.calls += 1
+        return [Result(self.boxes)]
+
+
+@pytest.fixture(scope='module')
+def ckpt(tmp_path_factory):
+    from safetensors.torch import save_file
+    d = str(tmp_path_factory.mktemp('InternVL'))
+    params = os.path.join(d, 'params')
+    os.makedirs(params)
+    # ---- tokenizer files (the reference's layout: tokenizer.model + tokenizer_config.json with the added tokens)
+    rng = random.Random(0)
+    corpus = os.path.join(d, 'corpus.txt')
+    alphabet = ['abcdefghijklmnopqrstuvwxyz', ' ', ' ', '，。？！：', '这幅书法作品内容是什么读出图中所有文字你是由上海人工智能实验室', 'ABCDEFGHIJ', '\n']
+    with open(corpus, 'w', encoding='utf-8') as f:
+        for _ in range(3000):
+            f.write(''.join(rng.choice(rng.choice(alphabet)) for _ in range(rng.randint(5, 60))).replace('\n', ' ') + '\n')
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(d, 'tokenizer'), vocab_size=500, model_type='bpe',
+                                   character_coverage=0.995, normalization_rule_name='identity', add_dummy_prefix=False,
+                                   remove_extra_whitespaces=False, byte_fallback=True, user_defined_symbols=['[UNUSED_TOKEN_140]'], minloglevel=2)
+    sp = spm.SentencePieceProcessor()
+    sp.Load(os.path.join(d, 'tokenizer.model'))
+    n = sp.get_piece_size()
+    dec = {'0': {'content': '<unk>', 'special': True}, '1': {'content': '<s>', 'special': True}, '2': {'content': '</s>', 'special': True}}
+    for i, t in enumerate(ADDED):
+        dec[str(n + i)] = {'content': t, 'special': True}
+    json.dump({'added_tokens_decoder': dec}, open(os.path.join(d, 'tokenizer_config.json'), 'w'))
+    vocab = n + len(ADDED)
+    # ---- weights: 1 layer of everything at full width, the reference's key names, two shards + index
+    dims = ModelDims.reduced(vit_layers=1, llm_layers=1, rs_depth=1, vocab=vocab)
+    sd = synthetic.make_state_dict(dims, seed=0)
+    model_keys = [k for k in sd if not k.startswith('calli.')]
+    half = len(model_keys) // 2
+    shards = {'model-00001-of-00002.safetensors': model_keys[:half], 'model-00002-of-00002.safetensors': model_keys[half:]}
+    weight_map = {}
+    for name, keys in shards.items():
+        save_file({k: sd[k].contiguous() for k in keys}, os.path.join(d, name))
+        weight_map.update({k: name for k in keys})
+    json.dump({'metadata': {}, 'weight_map': weight_map}, open(os.path.join(d, 'model.safetensors.index.json'), 'w'))
+    torch.save({'weight': torch.cat([sd['calli.mu'], sd['calli.sigma']], dim=1).float()}, os.path.join(params, 'gauss_norm_mu_sigma.pth'))
+    torch.save(synthetic.make_orderformer_state_dict(seed=11), os.path.join(params, 'orderformer.pth'))
+    cfg = {'downsample_ratio': 0.5,
+           'vision_config': dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, image_size=448, patch_size=14,
+                                 num_hidden_layers=1, layer_norm_eps=1e-6),
+           'llm_config': dict(hidden_size=4096, num_attention_heads=32, num_key_value_heads=8, intermediate_size=14336, num_hidden_layers=1,
+                              vocab_size=vocab, rms_norm_eps=1e-5, rope_theta=1000000, rope_scaling={'type': 'dynamic', 'factor': 2.0},
+                              max_position_embeddings=32768)}
+    json.dump(cfg, open(os.path.join(d, 'config.json'), 'w'))
+    # mu / sigma go through the fp32 .pth: the oracle must see the same values
+    sd['calli.mu'], sd['calli.sigma'] = sd['calli.mu'].float(), sd['calli.sigma'].float()
+    return dict(dir=d, params=params, dims=dims, sd=sd)
+
+
+@pytest.fixture(scope='module')
+def setup(ckpt):
+    from callireader_amd.modeling_internvl_chat import InternVLChatModel
+    from callireader_amd.tokenization_internlm2 import InternLM2Tokenizer
+    model = InternVLChatModel.from_pretrained(ckpt['dir'], params_dir=ckpt['params'], torch_dtype=torch.bfloat16, low_cpu_mem_usage=True,
+                                              trust_remote_code=True, max_tokens=4096, max_pages=2).eval().cuda()
+    tok = InternLM2Tokenizer.from_pretrained(ckpt['dir'])
+    assert model.dims == ckpt['dims'] and model.sorter is not None
+    model.aligned_token_id = tok.convert_tokens_to_ids('[UNUSED_TOKEN_140]')        # the reference hard-codes 92537 (:1100): toy vocabulary here
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 255, (500, 640, 3), dtype=np.uint8))
+    raw = [[300, 310, 380, 480], [10, 20, 110, 140], [200, 50, 420, 300], [12, 160, 108, 300]]
+    return dict(model=model, tok=tok, img=img, raw=raw, **ckpt)
+
+
+def oracle_answer(s, img, boxes, question, max_new, penalty):
+    """chat_ocr's pipeline from the CPU oracle with the real tokenizer: returns the decoded response."""
+    from oracle import vision, calli_align, generate
+    sd, dims, tok = s['sd'], s['dims'], s['tok']
+    IMG, REF, EOS = (tok.convert_tokens_to_ids(t) for t in ('<IMG_CONTEXT>', '[UNUSED_TOKEN_140]', '<|im_end|>'))
+    with torch.no_grad():
+        page_px = preprocess.load_image(img).to(torch.bfloat16)
+        feats = vision.extract_feature(sd, page_px, dims.vit_layers)
+        arr = np.array(img)
+        tiles = torch.cat([preprocess.load_image_2(Image.fromarray(arr[y1:y2, x1:x2])).to(torch.bfloat16) for x1, y1, x2, y2 in boxes])
+        rs = calli_align.resampler_forward(sd, vision.extract_feature(sd, tiles, dims.vit_layers), dims.rs_depth)
+        idx = calli_align.vq_cos_sim(sd['normed_emb.weight'], rs)
+        ref, _ = calli_align.denormalise(rs, idx.reshape(rs.shape[0], 3), sd['normed_emb.weight'], sd['calli.mu'], sd['calli.sigma'])
+        q = '<image>\n' + question + '[UNUSED_TOKEN_140]' * ref.shape[0]
+        t = get_conv_template('internlm2-chat')
+        t.append_message(t.roles[0], q)
+        t.append_message(t.roles[1], None)
+        query = t.get_prompt().replace('<image>', '<img>' + '<IMG_CONTEXT>' * 256 * page_px.shape[0] + '</img>', 1)
+        ids = tok(query, return_tensors='pt')['input_ids']
+        emb = generate.splice_embeddings(sd, ids, feats, ref, IMG, REF)
+        out = generate.greedy_generate(sd, dims.llm_layers, emb, max_new_tokens=max_new, eos_token_id=EOS, repetition_penalty=penalty)
+    return tok.batch_decode(out, skip_special_tokens=True)[0].split('<|im_end|>')[0].strip()
+
+
+def test_from_pretrained_chat_ocr_with_detector_object_and_real_tokenizer(setup):
+    from callireader_amd import ordering
+    m, tok, img = setup['model'], setup['tok'], setup['img']
+    det = YoloLike(setup['raw'])
+    gen = dict(num_beams=1, max_new_tokens=6, do_sample=False)
+    resp, hist = m.chat_ocr(tok, det, img, '这幅书法作品内容是什么？', gen, use_p=True, hard_vq=False, drop_zero=False, repetition_penalty=1.2,
+                            return_history=True, verbose=False)               # the reference's own call, inference.py:37-41
+    assert det.calls == 1
+    ordered = ordering.sort_boxes([list(b) for b in setup['raw']], img.width, img.height, m.sorter)
+    boxes = [tuple(int(v) for v in b[:4]) for b in ordered]
+    assert sorted(boxes) == sorted(tuple(b) for b in setup['raw'])
+    exp = oracle_answer(setup, img, boxes, '这幅书法作品内容是什么？', 6, 1.2)
+    assert resp == exp and hist[0][1] == resp
+    assert hist[0][0].count('[UNUSED_TOKEN_140]') == 3 * len(boxes)
+    # image given as a path, like inference.py does
+    p = os.path.join(setup['dir'], 'page.png')
+    img.save(p)
+    assert m.chat_ocr(tok, det, p, '这幅书法作品内容是什么？', gen, repetition_penalty=1.2) == exp
+
+
+def test_chat_ocr_pages_equals_per_page_calls(setup):
+    m, tok, img = setup['model'], setup['tok'], setup['img']
+    rng = np.random.default_rng(1)
+    img2 = Image.fromarray(rng.integers(0, 255, (460, 900, 3), dtype=np.uint8))
+    det = YoloLike(setup['raw'])
+    gen = dict(num_beams=1, max_new_tokens=5, do_sample=False)
+    singles = [m.chat_ocr(tok, det, im, '读出图中所有文字。', gen, repetition_penalty=1.0) for im in (img, img2)]
+    both = m.chat_ocr_pages(tok, det, [img, img2], '读出图中所有文字。', gen, repetition_penalty=1.0)
+    assert both == singles
+
+
+def test_dynamic_chat_and_generate(setup):
+    m, tok, img = setup['model'], setup['tok'], setup['img']
+    px = preprocess.load_image(img).to(torch.bfloat16).cuda()
+    gen = dict(num_beams=1, max_new_tokens=5, do_sample=False)
+    before = m.num_image_token
+    resp = m.dynamic_chat(tok, px[:1], 'hello', gen, use_p=True)
+    assert m.num_image_token == 3                                               # sticky, as upstream (:768-769)
+    query = ('<|im_start|>system你是由上海人工智能实验室联合商汤科技开发的书生多模态大模型，英文名叫InternVL, 是一个有用无害的人工智能助手。<|im_end|>\n'
+             '<|im_start|>userhello' + '<IMG_CONTEXT>' * 3 + '<|im_end|>\n<|im_start|>assistant')
+    exp = oracle_generate_one_tile(setup, px[:1].cpu(), query, 5)              # the oracle on the very tile the engine saw
+    assert resp == exp
+    # batch form: one answer per question, each equal to its own non-batched generate
+    m.num_image_token = 3
+    rs = m.dynamic_chat(tok, px[:2], ['alpha', 'beta'], gen, num_patches_list=[1, 1], batch=True, use_p=True)
+    assert isinstance(rs, list) and len(rs) == 2 and all(isinstance(r, str) for r in rs)
+    m.num_image_token = before
+
+
+def oracle_generate_one_tile(s, px, query, max_new):
+    from oracle import vision, calli_align, generate
+    sd, dims, tok = s['sd'], s['dims'], s['tok']
+    IMG, EOS = tok.convert_tokens_to_ids('<IMG_CONTEXT>'), tok.convert_tokens_to_ids('<|im_end|>')
+    with torch.no_grad():
+        feats = vision.extract_feature(sd, px, dims.vit_layers)
+        rs = calli_align.resampler_forward(sd, feats, dims.rs_depth)
+        idx = calli_align.vq_cos_sim(sd['normed_emb.weight'], rs)
+        pseudo, _ = calli_align.denormalise(rs, idx.reshape(rs.shape[0], 3), sd['normed_emb.weight'], sd['calli.mu'], sd['calli.sigma'])
+        ids = tok(query, return_tensors='pt')['input_ids']
+        emb = generate.splice_embeddings(sd, ids, pseudo.to(torch.bfloat16), None, IMG, -1)
+        out = generate.greedy_generate(sd, dims.llm_layers, emb, max_new_tokens=max_new, eos_token_id=EOS, repetition_penalty=1.0)
+    return tok.batch_decode(out, skip_special_tokens=True)[0].split('<|im_end|>')[0].strip()

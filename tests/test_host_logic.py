@@ -37,6 +37,24 @@ def test_dynamic_preprocess_tiles(size):
     assert [hashlib.md5(np.asarray(t).tobytes()).hexdigest() for t in tiles] == exp['md5']
 
 
+@pytest.mark.parametrize('size', sorted(GOLD.get('char_tiles', {})))
+def test_load_image_2_geometry_pinned_to_the_reference(size):
+    """The uint8 image the reference's load_image_2 (utils/utils.py:420-452) hands to its transform -- rescaled into
+    [200, 350], centred on white, one 448x448 tile -- for crops in all three scale regimes and degenerate sizes."""
+    w, h = (int(v) for v in size.split('x'))
+    img = Image.fromarray((np.arange(h * w * 3, dtype=np.uint32) * 7 % 253).astype(np.uint8).reshape(h, w, 3))
+    exp = GOLD['char_tiles'][size]
+    padded = preprocess.pad_char(img)
+    tiles = preprocess.dynamic_preprocess(padded, image_size=448, use_thumbnail=True, max_num=12)
+    assert len(tiles) == exp['n_tiles'] == 1 and list(np.asarray(tiles[0]).shape[:2]) == exp['size']
+    assert [hashlib.md5(np.asarray(t.convert('RGB')).tobytes()).hexdigest() for t in tiles] == exp['md5']
+    # the planner of the GPU path states the same geometry
+    job = preprocess.plan_char((0, 0, w, h), 0)
+    nw, nh, left, top, _, _ = preprocess.char_canvas(w, h)
+    assert (job['ow'], job['oh'], job['left'], job['top']) == (nw, nh, left, top)
+    assert preprocess.load_image_2(img).shape == (1, 3, 448, 448)
+
+
 def test_example_page_is_11_tiles_and_char_crop_is_one():
     assert preprocess.tile_grid(788, 2000) == (2, 5)                     # examples/0.jpg -> 10 + thumbnail
     assert preprocess.load_image(Image.new('RGB', (788, 2000))).shape == (11, 3, 448, 448)

@@ -107,14 +107,8 @@ def test_denormalise_pinned_to_the_reference_tail():
     """oracle.denormalise against what the reference's OWN statements (modeling_internvl_chat.py:602-640, compiled out of
     calli_align at generation time by scripts/make_golden_tail.py) produced: plain, drop_zero, hard VQ (incl. the
     cos == 0.5 boundary), both, a single tile; mu/sigma in fp32 and in bf16 (result dtype follows the promotion)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('make_golden_tail', os.path.join(ROOT, 'scripts', 'make_golden_tail.py'))
-    mgt = importlib.util.module_from_spec(spec)
-    sys.modules.setdefault('make_golden', type(sys)('make_golden'))       # the generator imports its sibling for paths only
-    sys.modules['make_golden'].install_stubs = lambda: None
-    sys.modules['make_golden'].OUT = GOLD
-    spec.loader.exec_module(mgt)
-    gold = np.load(os.path.join(GOLD, 'tail_vectors.npz'))
+    import tail_cases as mgt
+    gold = np.load(os.path.join(os.path.dirname(GOLD), 'tail_vectors.npz'))
     for name, seed, tiles, vocab, pdt, drop_zero, hard_vq in mgt.CASES:
         table, mu, sigma, x, idx, cos = mgt.make_case(seed, tiles, vocab, pdt, drop_zero, hard_vq)
         out, indices = calli_align.denormalise(x, idx, table, mu, sigma, drop_zero=drop_zero, hard_vq=hard_vq, cos=cos if hard_vq else None)

@@ -111,6 +111,25 @@ def test_real_model_chat_prompt_and_golden(real):
     assert out.split('<|im_end|>')[0].strip() == '君不见，黄河之水天上来'
 
 
+def test_wrapper_equals_the_reference_class(real):
+    """`wrapper` in the golden file was recorded from the REFERENCE's own InternLM2Tokenizer
+    (InternVL/tokenization_internlm2.py:34-235) loaded on its NUL-patched model (scripts/make_golden_tokenizer.py): ids
+    of every case (added-token splitting, BOS, the empty string), convert_tokens_to_ids, and batch_decode with
+    skip_special_tokens=True (what chat_ocr uses, modeling_internvl_chat.py:752)."""
+    d, sp, tok = real
+    gold = json.load(open(GOLD, encoding='utf-8'))
+    w = gold['wrapper']
+    assert w['ok'] and not w.get('mismatch_vs_library')
+    for item, ids in zip(gold['cases'], w['ids']):
+        assert tok(item['text'])['input_ids'] == ids, item['text']
+    for t, i in w['convert_tokens_to_ids'].items():
+        assert tok.convert_tokens_to_ids(t) == i, t
+    assert tok.batch_decode(w['decode_ids'], skip_special_tokens=True) == w['decode_skip_special']
+    # (decode_keep_special is recorded too, but spacing around kept specials is a transformers-version matter -- the file was
+    #  written under 5.x, the reference pins 4.45.2 -- and the path only ever decodes with skip_special_tokens=True, :752)
+    assert tok.batch_decode(torch.tensor(w['decode_ids'][:1]), skip_special_tokens=True) == w['decode_skip_special'][:1]
+
+
 def test_wrapper_on_trained_model(trained, tmp_path):
     sp, _ = trained
     # a checkpoint-dir layout with added tokens beyond the sentencepiece vocabulary, like the reference's
