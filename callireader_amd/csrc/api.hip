@@ -99,7 +99,7 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
         hipEventRecord(rec.b, st);
         const double n_out = epi == EPI_SWIGLU ? p.N / 2.0 : p.N;
         rec.flops = 2.0 * p.M * (double)p.N * p.K;
-        rec.bytes = 2.0 * ((double)p.N * p.K + (double)p.M * p.K) + (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out;
+        rec.bytes = 2.0 * ((double)p.N * p.K + (double)p.M * p.K) + (epi == EPI_ARGMAX ? 8.0 * p.M * ((p.N + 63) / 64) : (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out);
         rec.big = p.M >= 1024;
         c->prof_recs.push_back(rec);
         c->prof_issued++;

@@ -97,25 +97,23 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const bf16* __restrict
     *(bf16x8*)(out + r * D + tid * 16 + 8) = ob;
 }
 
-// similarity.max(dim=-1): first maximal index wins (torch semantics)
-__global__ __launch_bounds__(256) void row_argmax_bf16_kernel(const bf16* __restrict__ sim, int64_t ld, int n_cols,
-                                                              int64_t* __restrict__ idx, bf16* __restrict__ cosv) {
+// similarity.max(dim=-1) from the GEMM's per-block partials (EPI_ARGMAX: {bits(max bf16 value), column} per row and
+// 64-column block): larger value first, then the smaller column -- torch's first maximal index
+__global__ __launch_bounds__(256) void vq_pick_kernel(const unsigned long long* __restrict__ part, int64_t ld, int n_blk,
+                                                      int64_t* __restrict__ idx, bf16* __restrict__ cosv) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x;
     float best = -INFINITY; int besti = 0x7fffffff;
-    for (int c = tid; c < n_cols; c += 256) {
-        const float v = bf2f(sim[r * ld + c]);
-        if (v > best) { best = v; besti = c; }
+    for (int b = tid; b < n_blk; b += 256) {
+        const unsigned long long u = part[r * ld + b];
+        argmax_merge(best, besti, __uint_as_float((unsigned)(u >> 32)), (int)(unsigned)u);
     }
     bv[tid] = best; bi[tid] = besti;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            const float v2 = bv[tid + o]; const int i2 = bi[tid + o];
-            if (v2 > bv[tid] || (v2 == bv[tid] && i2 < bi[tid])) { bv[tid] = v2; bi[tid] = i2; }
-        }
+        if (tid < o) { float v = bv[tid]; int c = bi[tid]; argmax_merge(v, c, bv[tid + o], bi[tid + o]); bv[tid] = v; bi[tid] = c; }
         __syncthreads();
     }
     if (tid == 0) { idx[r] = bi[0]; if (cosv) cosv[r] = f2bf(bv[0]); }
@@ -181,7 +179,10 @@ int calli_finalize(cr_ctx* c, hipStream_t st) {
     t.dtype = CR_BF16; t.shape = tb->shape; t.bytes = tb->bytes;
     auto it = c->w.find("derived.vq_table");
     if (it != c->w.end() && it->second.bytes == t.bytes) t.ptr = it->second.ptr;
-    else CR_HIP(hipMalloc(&t.ptr, t.bytes));
+    else {
+        if (it != c->w.end() && it->second.ptr) CR_HIP(hipFree(it->second.ptr));      // a table of another size: release it
+        CR_HIP(hipMalloc(&t.ptr, t.bytes));
+    }
     // F.normalize(embedding_weight, p=2, dim=1) is input-independent: do it once (similarity.py:18 does it per call)
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)tb->shape[0]), dim3(256), 0, st, (const bf16*)tb->ptr, (bf16*)t.ptr, tb->shape[0]);
     CR_HIP(hipGetLastError());
@@ -189,16 +190,18 @@ int calli_finalize(cr_ctx* c, hipStream_t st) {
     return CR_OK;
 }
 
-extern "C" {
+// Tiles are independent through the resampler: chunks of RS_CHUNK tiles bound the scratch (the normed cat(x, latents) alone
+// is 2.1 MB per tile) and land the to_kv GEMM (259 rows per tile) just under a whole number of 256-CU rounds:
+// 252 x 259 = 65 268 rows = 255 row tiles x 4 column tiles = 3.98 rounds.
+static constexpr int RS_CHUNK = 252;
 
-int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
-    if (!c || !in || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_resample: bad argument");
-    CR_HIP(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+static size_t resample_ws(int T) {
+    const size_t R = (size_t)T * NQ;
+    return ((size_t)T * NKV * D + (size_t)T * NKV * 2 * INNER + R * D * 3 + R * INNER * 2 + R * D * 4) * 2 + 8192;
+}
+
+static int resample_chunk(cr_ctx* c, const bf16* x, int T, bf16* out, hipStream_t st) {
     const int64_t R = (int64_t)T * NQ;
-    const size_t need = ((size_t)T * NKV * D + (size_t)T * NKV * 2 * INNER + (size_t)R * D * 3 + (size_t)R * INNER * 2 +
-                         (size_t)R * D * 4) * 2 + 8192;
-    CR_TRY(ws_ensure(c, need));
     Arena ar(c->ws);
     bf16* kv_in = ar.take<bf16>((size_t)T * NKV * D);
     bf16* kv = ar.take<bf16>((size_t)T * NKV * 2 * INNER);
@@ -207,7 +210,6 @@ int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
     bf16* q = ar.take<bf16>((size_t)R * INNER);
     bf16* ao = ar.take<bf16>((size_t)R * INNER);
     bf16* ff = ar.take<bf16>((size_t)R * D * 4);
-    const bf16* x = (const bf16*)in;
 
     const bf16* l0 = W(c, "resampler.learns");
     if (!l0) return CR_ERR_STATE;
@@ -238,7 +240,21 @@ int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
     }
     const bf16 *nw = W(c, "resampler.norm.weight"), *nb = W(c, "resampler.norm.bias");
     if (!nw || !nb) return CR_ERR_STATE;
-    CR_TRY(ln(learns, (bf16*)out, nw, nb, R, 0, 0, 0, st));                                                        // :100
+    CR_TRY(ln(learns, out, nw, nb, R, 0, 0, 0, st));                                                               // :100
+    return CR_OK;
+}
+
+extern "C" {
+
+int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
+    if (!c || !in || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_resample: bad argument");
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    CR_TRY(ws_ensure(c, resample_ws(T < RS_CHUNK ? T : RS_CHUNK)));
+    for (int t0 = 0; t0 < T; t0 += RS_CHUNK) {
+        const int tc = T - t0 < RS_CHUNK ? T - t0 : RS_CHUNK;
+        CR_TRY(resample_chunk(c, (const bf16*)in + (size_t)t0 * 256 * D, tc, (bf16*)out + (size_t)t0 * NQ * D, st));
+    }
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
@@ -251,14 +267,23 @@ int cr_vq(cr_ctx* c, const void* in, int n, int64_t* idx, void* cosv, void* stre
     const DevTensor* tb = WT(c, "derived.vq_table");
     if (!tb) return CR_ERR_STATE;
     const int V = (int)tb->shape[0];
-    const int64_t ld = (V + 7) & ~7;
-    CR_TRY(ws_ensure(c, ((size_t)n * D + (size_t)n * ld) * 2 + 4096));
+    // The (n x 92 553) similarity is never written: the GEMM's epilogue keeps, per row and 64-column block, the first
+    // maximum of the bf16-rounded products (EPI_ARGMAX, 8 bytes), and vq_pick_kernel merges a row's 1447 partials.
+    // Rows go in chunks so that the normalised input and the partials stay under ~400 MB whatever n is.
+    const int n_blk = (V + 63) / 64;
+    const int64_t ldp = (n_blk + 1) & ~1;                          // 16-byte aligned rows
+    const int CH = 18432;                                           // 64 pages x 96 tiles x 3 queries: 72 row tiles of 256
+    const int nc = n < CH ? n : CH;
+    CR_TRY(ws_ensure(c, (size_t)nc * D * 2 + (size_t)nc * ldp * 8 + 4096));
     Arena ar(c->ws);
-    bf16* xn = ar.take<bf16>((size_t)n * D);
-    bf16* sim = ar.take<bf16>((size_t)n * ld);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(n), dim3(256), 0, st, (const bf16*)in, xn, (int64_t)n);
-    CR_TRY(gemm(c, EPI_STORE, xn, D, (const bf16*)tb->ptr, D, sim, ld, nullptr, nullptr, 0, n, V, D, st));
-    hipLaunchKernelGGL(row_argmax_bf16_kernel, dim3(n), dim3(256), 0, st, sim, ld, V, idx, (bf16*)cosv);
+    bf16* xn = ar.take<bf16>((size_t)nc * D);
+    unsigned long long* part = ar.take<unsigned long long>((size_t)nc * ldp);
+    for (int r0 = 0; r0 < n; r0 += CH) {
+        const int m = n - r0 < CH ? n - r0 : CH;
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(m), dim3(256), 0, st, (const bf16*)in + (size_t)r0 * D, xn, (int64_t)m);
+        CR_TRY(gemm(c, EPI_ARGMAX, xn, D, (const bf16*)tb->ptr, D, part, ldp, nullptr, nullptr, 0, m, V, D, st));
+        hipLaunchKernelGGL(vq_pick_kernel, dim3(m), dim3(256), 0, st, part, ldp, n_blk, idx + r0, cosv ? (bf16*)cosv + r0 : nullptr);
+    }
     CR_HIP(hipGetLastError());
     return CR_OK;
 }

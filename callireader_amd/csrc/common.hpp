@@ -112,6 +112,7 @@ enum GemmEpi {
     EPI_PATCH = 5,    // patch-embed: bf16(bf16(acc + bias) + pos[1 + m % G]) -> row (m / G) * (G + 1) + 1 + m % G
     EPI_F32 = 6,      // float(bf16(acc + bias))                            (logits: bf16 GEMM then .float())
     EPI_PARTIAL = 7,  // decode only (M <= 64): fp32 partial sums [S][M][N] of S K-slices, no bias; the consumer kernel sums them
+    EPI_ARGMAX = 8,   // cosine VQ: C[m][b] = {col, bits(max)} of bf16(acc) over the 64 columns of block b (first max wins); nothing else stored
 };
 
 struct GemmParams {
@@ -125,6 +126,16 @@ struct GemmParams {
     int group;                 // EPI_PATCH: patches per tile (1024)
     int kernel;                // 0 = dispatcher's choice; 128 | 256 | 1 (skinny) pin one (cr_op_gemm's tests only)
 };
+
+// EPI_ARGMAX partial of one row and one 64-column block: the bf16-rounded maximum (as fp32 bits, high word) and its column
+// (low word); -inf / column 0x7fffffff for a block with no valid column.  Merging takes the larger value, then the
+// smaller column: torch.max's first-index rule (models/similarity.py:21).
+__device__ __forceinline__ void argmax_merge(float& bv, int& bc, float v, int c) {
+    if (v > bv || (v == bv && c < bc)) { bv = v; bc = c; }
+}
+__device__ __forceinline__ unsigned long long argmax_pack(float v, int c) {
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)c;
+}
 
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
 // K-slices of the EPI_PARTIAL decode GEMM for an [N, K] weight (depends on N and K only, never on M); 0 = unsupported

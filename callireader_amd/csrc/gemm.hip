@@ -158,6 +158,7 @@ int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
         case EPI_SWIGLU: return (p.N % 16 == 0) ? launch_t<EPI_SWIGLU>(p, stream) : CR_ERR_ARG;
         case EPI_PATCH: return (p.res && p.group > 0) ? launch_t<EPI_PATCH>(p, stream) : CR_ERR_ARG;
         case EPI_F32: return launch_t<EPI_F32>(p, stream);
+        case EPI_ARGMAX: return launch_t<EPI_ARGMAX>(p, stream);
     }
     return CR_ERR_ARG;
 }

@@ -155,6 +155,31 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
         }
     }
 
+    if (EPI == EPI_ARGMAX) {
+        // cosine VQ (models/similarity.py:19-21): per row the maximum of bf16(acc) over this wave's 64 columns and its
+        // first column; a lane holds 16 of a row's 64 values (columns j*16 + g*4 + e), the four lane groups g meet through
+        // two shuffles.  One 8-byte partial per (row, 64-column block) leaves the kernel; the similarity never does.
+        const int r = lane & 15, g = lane >> 4;
+        const int64_t blk = col0 >> 6;
+#pragma unroll
+        for (int mf = 0; mf < 8; mf++) {
+            float bv = -INFINITY; int bc = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int n = col0 + j * 16 + g * 4 + e;
+                    float v = rbf(acc[mf][j][e] + (has_bias ? bias_f[j][e] : 0.f));
+                    v = n < p.N ? v : -INFINITY;
+                    if (v > bv) { bv = v; bc = n; }              // ascending columns inside a lane: strict > keeps the first
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) argmax_merge(bv, bc, __shfl_xor(bv, o, 64), __shfl_xor(bc, o, 64));
+            const int gm = row_base + mf * 16 + r;
+            if (g == 0 && gm < p.M && col0 < p.N) ((unsigned long long*)p.C)[(int64_t)gm * p.ldc + blk] = argmax_pack(bv, bc);   // blocks past N do not exist
+        }
+        return;
+    }
     if (EPI == EPI_SWIGLU) {
         // staged columns are [8 gate | 8 up] per 16: a lane takes one such pair -> 8 outputs
         const int r = lane >> 2, oc = lane & 3;
@@ -427,6 +452,7 @@ int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream) {
         case EPI_SWIGLU: return launch_t<EPI_SWIGLU>(p, stream);
         case EPI_PATCH: return launch_t<EPI_PATCH>(p, stream);
         case EPI_F32: return launch_t<EPI_F32>(p, stream);
+        case EPI_ARGMAX: return launch_t<EPI_ARGMAX>(p, stream);
     }
     return CR_ERR_ARG;
 }

@@ -77,6 +77,19 @@ __device__ __forceinline__ void epilogue_scalar(const GemmParams& p, int gm, int
 // rows [row0, row0+64) x cols [col0, col0+64) of the output from the wave-private stage `st`
 template <int EPI>
 __device__ __forceinline__ void epilogue_subtile(const GemmParams& p, const float* st, int row0, int col0, int lane) {
+    if (EPI == EPI_ARGMAX) {
+        // lane = row of the 64 x 64 sub-tile: first maximum of bf16(acc + bias) over its 64 columns -> one 8-byte partial
+        const int gm = row0 + lane;
+        float bv = -INFINITY; int bc = 0x7fffffff;
+        for (int c = 0; c < 64; c++) {
+            const int n = col0 + c;
+            float v = rbf(st[lane * STAGE_LD + c] + (p.bias && n < p.N ? bf2f(p.bias[n]) : 0.f));
+            v = n < p.N ? v : -INFINITY;
+            if (v > bv) { bv = v; bc = n; }
+        }
+        if (gm < p.M && col0 < p.N) ((unsigned long long*)p.C)[(int64_t)gm * p.ldc + (col0 >> 6)] = argmax_pack(bv, bc);
+        return;
+    }
     if (EPI == EPI_SWIGLU) {
         // staged columns: [8 gate | 8 up] x 4 per 64-wide row -> 32 outputs per row
 #pragma unroll

@@ -251,6 +251,8 @@ def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torc
     mrows = M if epi != 5 else (M // group) * (group + 1)
     if epi == 7:                     # fp32 K-slice partial sums [S <= 8][M][N]; unused slabs stay zero
         mrows, out_dtype = 8 * M, torch.float32
+    if epi == 8:                     # cosine-VQ partials: per row and 64-column block {column (low word), bits of the bf16 max (high word)}
+        ncols, out_dtype = ((N + 63) // 64 + 1) & ~1, torch.int64
     Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
     B.check(B.lib.cr_op_gemm(epi | (kernel << 8), _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')

@@ -164,7 +164,9 @@ int cr_orderformer(cr_ctx* ctx, const void* boxes, int B, int L, float* scores, 
 
 /* ---- single operators (unit-parity tests and profiling) --------------------------------------- */
 /* C = epi(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch, 6 f32,
- * 7 decode partial sums (M <= 64, no bias: C = fp32 [S][M][N], S <= 8 K-slices summed by the consumer).
+ * 7 decode partial sums (M <= 64, no bias: C = fp32 [S][M][N], S <= 8 K-slices summed by the consumer),
+ * 8 row arg-max partials (cosine VQ: C = uint64 [M][ldc], one per row and 64-column block: bits of the bf16-rounded maximum in the
+ *   high word, its first column in the low word; M > 64 tile kernels only).
  * Bits 8..15 of epi pin a kernel for the unit tests: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent,
  * 3 weight-streaming (M <= 64); a pinned kernel that cannot take the shape returns CR_ERR_ARG. */
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,

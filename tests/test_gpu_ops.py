@@ -340,6 +340,30 @@ def test_gemm_skinny_k_sliced_partials(E, M, N, K):
     torch.testing.assert_close(total, A.float() @ W.float().t(), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize('M,N,K,kern', [(300, 1000, 128, 1), (2304, 1000, 128, 2), (2100, 4100, 256, 2), (70, 130, 64, 1)])
+def test_gemm_row_argmax_partials(E, M, N, K, kern):
+    """EPI_ARGMAX (cosine VQ, models/similarity.py:19-21): per row and 64-column block the first maximum of bf16(A.W^T).
+    Small-integer data make the products exact and full of ties, so the first-index rule is what is being tested;
+    ragged N, ragged M."""
+    g = torch.Generator().manual_seed(40 + M)
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    W = torch.randint(-2, 3, (N, K), generator=g).float()
+    W[7] = W[3]                                                    # duplicated table rows: equal similarity, index 3 must win over 7
+    W[N - 1] = W[N - 2]
+    out = E.op_gemm(8, bf(A).to(dev()), bf(W).to(dev()), kernel=kern)
+    torch.cuda.synchronize()
+    sim = rb(A @ W.t())
+    nblk = (N + 63) // 64
+    part = out[:, :nblk].cpu()
+    val = ((part >> 32) & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
+    col = (part & 0xFFFFFFFF).to(torch.int64)
+    for b in range(nblk):
+        blk = sim[:, b * 64:(b + 1) * 64]
+        mx, am = blk.max(dim=1)                                    # torch: first maximal index
+        assert torch.equal(val[:, b], mx), b
+        assert torch.equal(col[:, b], am + b * 64), b
+
+
 def test_gemm_rejects_bad_k(E):
     A = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
     W = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
