@@ -380,6 +380,47 @@ def main():
             result['ordering_f4'] = {'workload': 'OrderFormer (4 layers, d 256, 8 heads) on 64 pages x 50 boxes, bf16',
                                      'gpu_ms_per_page': round(of_gpu_ms / 64, 4), 'cpu_oracle_ms_per_page': round(of_cpu_ms, 2),
                                      'parity': 'scores within 4 % of the oracle model, reading order = the reference on 5 pages (tests/test_gpu_ordering.py)'}
+        if not args.no_vit_extra:
+            # BASELINE config 5's option, as an EXTRA (the headline above is bf16, the reference's arithmetic): batched decode
+            # on e4m3 copies of the LLM's linear weights.  Same pages, same prompts; 32 decode steps each way.
+            pseudo_all, _ = model.align_tiles(char_px)
+            vit_mine = model.extract_feature(page_px)
+            pr = pseudo_all.reshape(-1, 3, dims.llm_hidden)
+            embeds = [eng.embed_splice(ids[j], vit_mine[j * PAGE_TILES:(j + 1) * PAGE_TILES], pr[p * CHAR_TILES:(p + 1) * CHAR_TILES],
+                                       img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID) for j, p in enumerate(mine)]
+            del pseudo_all, vit_mine
+
+            def decode_run(n_steps=32):
+                kv = model.kv()
+                kv.reset()
+                for i0 in range(0, len(embeds), 16):
+                    idx = list(range(i0, min(len(embeds), i0 + 16)))
+                    eng.prefill_batch(kv, idx, [embeds[i] for i in idx])
+                live = list(range(len(embeds)))
+                first = eng.decode(kv, live, want_logits=True).float()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_steps):
+                    eng.decode(kv, live)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n_steps
+                return dt, first, [kv.generated(i)[:n_steps + 2] for i in live]
+            dt16, lg16, ids16 = decode_run()
+            eng.enable_fp8_decode(True)
+            decode_run(4)
+            dt8, lg8, ids8 = decode_run()
+            eng.enable_fp8_decode(False)
+            same = sum(a == b for x, y in zip(ids16, ids8) for a, b in zip(x[:2], y[:2]))
+            result['fp8_decode'] = {'what': 'batched greedy decode with e4m3 copies of the LLM linear weights (one fp32 scale per output row, dequantised '
+                                            'in registers, same bf16 MFMA, fp32 accumulation; activations / KV cache / prefill / vision stay bf16) '
+                                            'next to the bf16 path on the same pages: an option, not the headline',
+                                    'pages': len(embeds), 'bf16_ms_per_step': round(dt16 * 1e3, 3), 'fp8_ms_per_step': round(dt8 * 1e3, 3),
+                                    'speedup': round(dt16 / dt8, 3),
+                                    'first_step_logits_rel_l2_vs_bf16': round(float((lg8 - lg16).double().norm() / lg16.double().norm()), 4),
+                                    'first_two_picks_equal': f'{same}/{2 * len(embeds)}',
+                                    'note': 'random-init weights: every linear adds ~3.6 % of independent relative noise (tests/test_gpu_fp8.py); '
+                                            'accuracy on real weights is what evaluate.py --type full_page measures (needs the checkpoint and CalliBench)'}
+            del embeds
         if not args.no_cpu_baseline:
             del model
             result['cpu_baseline'] = cpu_baseline()

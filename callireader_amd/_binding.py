@@ -51,6 +51,8 @@ SIGNATURES = {
     'cr_llm_prefill': (i32, [vp, vp, i32, vp, i32, f32, vp, vp]),
     'cr_llm_prefill_batch': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, C.POINTER(C.c_int32), f32, vp, vp]),
     'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, f32, vp, vp]),
+    'cr_enable_fp8_decode': (i32, [vp, i32, vp]),
+    'cr_op_quantize_fp8': (i32, [vp, i64, i32, i32, vp, vp, vp]),
     'cr_profile': (i32, [vp, i32]),
     'cr_profile_read': (i32, [vp, C.POINTER(C.c_double)]),
     'cr_profile_stats': (i32, [vp, C.POINTER(i64)]),

@@ -99,7 +99,7 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
         hipEventRecord(rec.b, st);
         const double n_out = epi == EPI_SWIGLU ? p.N / 2.0 : p.N;
         rec.flops = 2.0 * p.M * (double)p.N * p.K;
-        rec.bytes = 2.0 * ((double)p.N * p.K + (double)p.M * p.K) + (epi == EPI_ARGMAX ? 8.0 * p.M * ((p.N + 63) / 64) : (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out);
+        rec.bytes = (p.w8 ? 1.0 : 2.0) * (double)p.N * p.K + 2.0 * (double)p.M * p.K + (epi == EPI_ARGMAX ? 8.0 * p.M * ((p.N + 63) / 64) : (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out);
         rec.big = p.M >= 1024;
         c->prof_recs.push_back(rec);
         c->prof_issued++;
@@ -109,7 +109,7 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
     return CR_OK;
 }
 
-static size_t dtype_size(int dt) { return dt == CR_BF16 ? 2 : dt == CR_F32 ? 4 : dt == CR_I64 ? 8 : dt == CR_I32 ? 4 : 0; }
+static size_t dtype_size(int dt) { return dt == CR_BF16 ? 2 : dt == CR_F32 ? 4 : dt == CR_I64 ? 8 : dt == CR_I32 ? 4 : 0; }   // CR_U8 is internal: not loadable
 
 extern "C" {
 
@@ -202,6 +202,7 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     p.M = M; p.N = N; p.K = K; p.group = group;
     const int kern = (epi >> 8) & 0xff;           // tests pin a kernel: 1 = 128x128, 2 = 256x256, 3 = skinny
     p.kernel = kern == 1 ? 128 : kern == 2 ? 256 : kern == 3 ? 1 : 0;
+    if (epi & (1 << 16)) { p.w8 = 1; p.wscale = (const float*)scale; p.scale = nullptr; }      // e4m3 weights + per-row fp32 scales
     epi &= 0xff;
     int r = launch_gemm(epi, p, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_gemm(epi=%d, M=%d, N=%d, K=%d) rejected or failed to launch", epi, M, N, K);

@@ -125,6 +125,9 @@ struct GemmParams {
     int M, N, K;
     int group;                 // EPI_PATCH: patches per tile (1024)
     int kernel;                // 0 = dispatcher's choice; 128 | 256 | 1 (skinny) pin one (cr_op_gemm's tests only)
+    // fp8 weight streaming (decode, M <= 64 only): W points at e4m3 bytes [N][ldw], wscale[n] restores row n (C = (X . W8^T) * wscale)
+    int w8;
+    const float* wscale;
 };
 
 // EPI_ARGMAX partial of one row and one 64-column block: the bf16-rounded maximum (as fp32 bits, high word) and its column

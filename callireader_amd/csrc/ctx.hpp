@@ -26,6 +26,7 @@ struct cr_ctx {
     hipStream_t side = nullptr;         // blocking stream the decode graph is captured into and replayed on when the caller's stream is the
                                         // null stream (which cannot be captured); implicitly ordered with it
     uint64_t weight_gen = 0;            // bumped by cr_load_weight / cr_finalize: captured graphs hold weight pointers
+    bool fp8_decode = false;            // cr_enable_fp8_decode: batched decode streams e4m3 copies of the LLM's linear weights (half the bytes)
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
     std::unordered_map<std::string, DevTensor> w;
     // workspace

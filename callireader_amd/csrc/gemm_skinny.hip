@@ -13,6 +13,11 @@
 //   * partial tiles of the waves are summed through LDS in a fixed order (bitwise reproducible, and a row's
 //     result does not depend on how many other rows are in the batch);
 //   * epilogues: store / +residual / SwiGLU (rows [8 gate | 8 up] of one tile -> 8 outputs) / fp32 logits.
+//   * W8: the weights are e4m3 bytes with one fp32 scale per row (llm.hip: cr_enable_fp8_decode) -- half the HBM bytes of the
+//     kernel's bound.  A lane loads 16 B = 16 consecutive k of its row per 64-deep step and turns them into two bf16
+//     fragments with v_cvt_scalef32_pk_bf16_fp8 (exact: e4m3 is a subset of bf16); the X fragments take the same k
+//     (16*(lane>>4) + 0..7 and + 8..15), the MFMA, the accumulation and the epilogue stay as they are, and the row scale
+//     multiplies the fp32 sum once, before the epilogue's rounding.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -20,7 +25,16 @@
 
 namespace {
 
-template <int EPI, int WAVES, int MT, int RT = 1>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// 8 e4m3 bytes (two dwords) -> one bf16x8 MFMA fragment
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned lo, unsigned hi) {
+    const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+template <int EPI, int WAVES, int MT, int RT = 1, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParams p) {
     // RT = 16-row weight tiles per wave: X fragments are loaded once per RT tiles (X re-reads through L2 are the
     // bottleneck once M > 16), used where N is large enough to still fill the chip
@@ -47,7 +61,59 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
 #pragma unroll
         for (int t = 0; t < MT; t++) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int ks = 0;
+    if (W8) {
+        // 64-deep steps: per step a lane holds k = 16*(lane>>4) + 0..15 of its weight row (one 16-B load) and of each X row
+        // (two 16-B loads); fragment h (h = 0, 1) pairs the weights' bytes 8h..8h+7 with the X chunk at + 8h
+        const int steps = ksteps / 2;
+        const int kq16 = (lane >> 4) * 16;
+        const unsigned char* w8p[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) w8p[r] = (const unsigned char*)p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq16;
+        const bf16* x8p[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) x8p[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq16;
+        constexpr int U8 = UR > 1 ? UR / 2 : 1;               // 64-deep steps in flight per batch
+        int s8 = 0;
+        for (; s8 + U8 <= steps; s8 += U8) {
+            u32x4_t w[RT][U8];
+            bf16x8 x[MT][U8][2];
+#pragma unroll
+            for (int r = 0; r < RT; r++)
+#pragma unroll
+                for (int u = 0; u < U8; u++) w[r][u] = __builtin_nontemporal_load((const u32x4_t*)(w8p[r] + (s8 + u) * 64));
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int u = 0; u < U8; u++) {
+                    x[t][u][0] = *(const bf16x8*)(x8p[t] + (s8 + u) * 64);
+                    x[t][u][1] = *(const bf16x8*)(x8p[t] + (s8 + u) * 64 + 8);
+                }
+#pragma unroll
+            for (int u = 0; u < U8; u++)
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const bf16x8 w0 = fp8x8_to_bf16(w[r][u][0], w[r][u][1]), w1 = fp8x8_to_bf16(w[r][u][2], w[r][u][3]);
+#pragma unroll
+                    for (int t = 0; t < MT; t++) {
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[t][u][0], acc[r][t], 0, 0, 0);
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x[t][u][1], acc[r][t], 0, 0, 0);
+                    }
+                }
+        }
+        for (; s8 < steps; s8++) {
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const u32x4_t w = __builtin_nontemporal_load((const u32x4_t*)(w8p[r] + s8 * 64));
+                const bf16x8 w0 = fp8x8_to_bf16(w[0], w[1]), w1 = fp8x8_to_bf16(w[2], w[3]);
+#pragma unroll
+                for (int t = 0; t < MT; t++) {
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, *(const bf16x8*)(x8p[t] + s8 * 64), acc[r][t], 0, 0, 0);
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, *(const bf16x8*)(x8p[t] + s8 * 64 + 8), acc[r][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    int ks = W8 ? ksteps : 0;
     for (; ks + UR <= ksteps; ks += UR) {
         bf16x8 w[RT][UR], x[MT][UR];
 #pragma unroll
@@ -91,6 +157,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) s += red[w][t][n][m];
+        if (W8) s *= p.wscale[min(n0 + (t / MT) * 16 + n, p.N - 1)];      // fp8 weights: the row's scale, once, on the fp32 sum
         red[0][t][n][m] = s;       // own element only: no hazard with other threads' reads
     }
     __syncthreads();
@@ -126,18 +193,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
     }
 }
 
-template <int EPI, int WAVES, int RT>
-int launch_mt(const GemmParams& p, hipStream_t stream, int splits = 1) {
+template <int EPI, int WAVES, int RT, bool W8>
+int launch_mt8(const GemmParams& p, hipStream_t stream, int splits) {
     const int mt = (p.M + 15) / 16;
     const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), splits), block(WAVES * 64);
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 1, RT>), grid, block, 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 2, RT>), grid, block, 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 3, RT>), grid, block, 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 4, RT>), grid, block, 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 1, RT, W8>), grid, block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 2, RT, W8>), grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 3, RT, W8>), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, WAVES, 4, RT, W8>), grid, block, 0, stream, p); break;
         default: return CR_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+template <int EPI, int WAVES, int RT>
+int launch_mt(const GemmParams& p, hipStream_t stream, int splits = 1) {
+    if (p.w8) {
+        if (p.K % (64 * WAVES * splits) != 0 || !p.wscale) return CR_ERR_ARG;      // 64-deep steps per wave
+        return launch_mt8<EPI, WAVES, RT, true>(p, stream, splits);
+    }
+    return launch_mt8<EPI, WAVES, RT, false>(p, stream, splits);
 }
 
 template <int EPI>
@@ -188,6 +264,7 @@ int gemm_partial_splits(int N, int K) { return partial_geom(N, K).splits; }
 
 bool gemm_skinny_supported(int epi, const GemmParams& p) {
     if (p.M > 64 || p.K % 128 != 0) return false;
+    if (p.w8 && (p.K % 512 != 0 || !p.wscale || (p.ldw & 15))) return false;
     if (epi == EPI_PARTIAL) return p.bias == nullptr && partial_geom(p.N, p.K).splits > 0;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;

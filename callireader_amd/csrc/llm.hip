@@ -219,6 +219,38 @@ __global__ __launch_bounds__(256) void interleave8_kernel(const bf16* __restrict
     dp[threadIdx.x + 256] = sp[threadIdx.x + 256];
 }
 
+// One weight row -> e4m3 bytes + its scale: scale = max|w| / 448 (the largest e4m3 magnitude), q = round-to-nearest-even
+// (w / scale); an all-zero row keeps scale 1.  One workgroup per row, K % 8 == 0.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restrict__ w, int64_t ldw, int K, unsigned char* __restrict__ q,
+                                                              float* __restrict__ scale) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bf16* wr = w + r * ldw;
+    float mx = 0.f;
+    for (int k = tid * 8; k < K; k += 256 * 8) {
+        const bf16x8 v = *(const bf16x8*)(wr + k);
+#pragma unroll
+        for (int e = 0; e < 8; e++) mx = fmaxf(mx, fabsf(bf2f(v[e])));
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    if (tid == 0) scale[r] = sc;
+    for (int k = tid * 8; k < K; k += 256 * 8) {
+        const bf16x8 v = *(const bf16x8*)(wr + k);
+        unsigned lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[0]) * inv, bf2f(v[1]) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[2]) * inv, bf2f(v[3]) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[4]) * inv, bf2f(v[5]) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[6]) * inv, bf2f(v[7]) * inv, hi, true);
+        *(uint2*)(q + r * (int64_t)K + k) = make_uint2(lo, hi);
+    }
+}
+
 int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
          int M, int N, int K, hipStream_t st) {
     GemmParams p{};
@@ -232,13 +264,31 @@ int rms(const bf16* in, int64_t ld_in, bf16* out, const bf16* w, int64_t rows, f
     return launch_rmsnorm(np, D, st);
 }
 
-struct LayerW { const bf16 *an, *fn, *wqkv, *wo, *w13, *w2; };
+// the same GEMM on the e4m3 copy of a weight (decode only): C = (A . W8^T) * wscale
+int gemm8(cr_ctx* c, int epi, const bf16* A, int64_t lda, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc, const bf16* res,
+          int64_t ldr, int M, int N, int K, hipStream_t st) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = (const bf16*)w8->ptr; p.ldw = K; p.C = C; p.ldc = ldc; p.res = res; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
+    p.w8 = 1; p.wscale = (const float*)ws->ptr;
+    return ctx_gemm(c, epi, p, st);
+}
+
+struct LayerW { const bf16 *an, *fn, *wqkv, *wo, *w13, *w2; const DevTensor *q_qkv, *s_qkv, *q_o, *s_o, *q_13, *s_13, *q_2, *s_2; };
+
+const DevTensor* opt(cr_ctx* c, const std::string& name) {
+    auto it = c->w.find(name);
+    return it == c->w.end() ? nullptr : &it->second;
+}
 
 int layer_weights(cr_ctx* c, int l, LayerW& w) {
     const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
     w.an = W(c, p + "attention_norm.weight"); w.fn = W(c, p + "ffn_norm.weight");
     w.wqkv = W(c, p + "attention.wqkv.weight"); w.wo = W(c, p + "attention.wo.weight");
     w.w13 = W(c, "derived.w13." + std::to_string(l)); w.w2 = W(c, p + "feed_forward.w2.weight");
+    w.q_qkv = opt(c, "fp8." + p + "attention.wqkv.weight"); w.s_qkv = opt(c, "fp8s." + p + "attention.wqkv.weight");
+    w.q_o = opt(c, "fp8." + p + "attention.wo.weight"); w.s_o = opt(c, "fp8s." + p + "attention.wo.weight");
+    w.q_13 = opt(c, "fp8.derived.w13." + std::to_string(l)); w.s_13 = opt(c, "fp8s.derived.w13." + std::to_string(l));
+    w.q_2 = opt(c, "fp8." + p + "feed_forward.w2.weight"); w.s_2 = opt(c, "fp8s." + p + "feed_forward.w2.weight");
     return (w.an && w.fn && w.wqkv && w.wo && w.w13 && w.w2) ? CR_OK : CR_ERR_STATE;
 }
 
@@ -272,8 +322,11 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
         if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
-        if (sliced) CR_TRY(gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st));
-        else CR_TRY(gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
+        const bool f8 = decode && M <= 64 && c->fp8_decode && w.q_qkv && w.s_qkv && w.q_o && w.s_o && w.q_13 && w.s_13 && w.q_2 && w.s_2;
+        if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st)
+                               : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st));
+        else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st)
+                        : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
         hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
                            decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens,
                            (const float*)(sliced ? pbuf : nullptr), s_qkv);
@@ -299,15 +352,19 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             if (launch_flash_attn_split(ap, HD, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
         }
         if (sliced) {
-            CR_TRY(gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st));
+            CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, ao, D, w.q_o, w.s_o, pbuf, D, nullptr, 0, M, D, D, st)
+                      : gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st));
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_o, M, w.fn, h, c->d.rms_eps, st));
         } else {
-            CR_TRY(gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+            CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st)
+                      : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
             CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
         }
-        CR_TRY(gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
+        CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st)
+                  : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
         if (sliced) {
-            CR_TRY(gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st));
+            CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, act, ff, w.q_2, w.s_2, pbuf, D, nullptr, 0, M, D, ff, st)
+                      : gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st));
             const bf16* next_norm = nullptr;             // the last layer's sum only lands in x: the caller norms what it needs
             if (l + 1 < c->d.llm_layers) {
                 LayerW wn;
@@ -316,7 +373,8 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             }
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_2, M, next_norm, h, c->d.rms_eps, st));
         } else {
-            CR_TRY(gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
+            CR_TRY(f8 ? gemm8(c, EPI_RES, act, ff, w.q_2, w.s_2, x, D, x, D, M, D, ff, st)
+                      : gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
         }
     }
     CR_HIP(hipGetLastError());
@@ -359,6 +417,53 @@ int llm_finalize(cr_ctx* c, hipStream_t st) {
 }
 
 extern "C" {
+
+int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float* scale, void* stream) {
+    if (!w || !q || !scale || N <= 0 || K <= 0 || (K & 7) || (ldw & 7)) return cr_fail(CR_ERR_ARG, "cr_op_quantize_fp8: bad argument");
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16*)w, ldw, K, (unsigned char*)q, scale);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
+    if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: null context");
+    if (!enable) { c->fp8_decode = false; return CR_OK; }
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: call cr_finalize first");
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<std::string> names;
+    for (int l = 0; l < c->d.llm_layers; l++) {
+        const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
+        names.push_back(p + "attention.wqkv.weight"); names.push_back(p + "attention.wo.weight");
+        names.push_back("derived.w13." + std::to_string(l)); names.push_back(p + "feed_forward.w2.weight");
+    }
+    names.push_back("language_model.output.weight");
+    for (const std::string& nm : names) {
+        const DevTensor* src = WT(c, nm);
+        if (!src) return CR_ERR_STATE;
+        const int64_t N = src->shape[0], K = src->shape[1];
+        if ((K % 512) != 0) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: %s has K = %lld, not a multiple of 512", nm.c_str(), (long long)K);
+        auto have = c->w.find("fp8." + nm);
+        if (have != c->w.end() && have->second.shape == src->shape && c->w.count("fp8s." + nm)) continue;     // built already for these weights
+        DevTensor q, s;
+        q.dtype = CR_U8; q.shape = src->shape; q.bytes = (size_t)N * K;
+        s.dtype = CR_F32; s.shape = {N}; s.bytes = (size_t)N * 4;
+        if (hipMalloc(&q.ptr, q.bytes) != hipSuccess || hipMalloc(&s.ptr, s.bytes) != hipSuccess)
+            return cr_fail(CR_ERR_NOMEM, "cr_enable_fp8_decode: %s", nm.c_str());
+        hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, st, (const bf16*)src->ptr, K, (int)K, (unsigned char*)q.ptr, (float*)s.ptr);
+        for (const char* pre : {"fp8.", "fp8s."}) {
+            auto old = c->w.find(pre + nm);
+            if (old != c->w.end()) { hipFree(old->second.ptr); c->w.erase(old); }
+        }
+        c->w["fp8." + nm] = q;
+        c->w["fp8s." + nm] = s;
+    }
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipStreamSynchronize(st));
+    c->fp8_decode = true;
+    c->weight_gen++;
+    return CR_OK;
+}
 
 int cr_embed_splice(cr_ctx* c, const int64_t* ids, int S, const void* vit, int n_vit, int64_t img_id, const void* ref,
                     int n_ref, int64_t ref_id, void* out, void* stream) {
@@ -537,7 +642,9 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
         hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, table, force_tokens, kv->d_seqs, kv->d_gen, kv->d_ngen, kv->gen_cap, x);
         CR_TRY(run_layers(c, kv, x, n, true, {}, nullptr, nullptr, kv->d_seqs, nsplit, st));
         CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
-        CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
+        const DevTensor *q_out = opt(c, "fp8.language_model.output.weight"), *s_out = opt(c, "fp8s.language_model.output.weight");
+        if (c->fp8_decode && n <= 64 && q_out && s_out) CR_TRY(gemm8(c, EPI_F32, hl, D, q_out, s_out, lg, V, nullptr, 0, n, V, D, st));
+        else CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
         if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(pick_kernel, dim3(n), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, 0, kv->d_seqs, kv->d_gen, kv->d_ngen,
                            kv->d_len, kv->gen_cap, 1);

@@ -81,6 +81,11 @@ class Engine:
     def finalize(self):
         B.check(B.lib.cr_finalize(self._h, _stream()), 'cr_finalize')
 
+    def enable_fp8_decode(self, on=True):
+        """Batched decode streams e4m3 copies of the LLM's linear weights (one fp32 scale per output row) instead of the
+        bf16 ones: half the HBM bytes per step.  Off by default: the reference computes in bf16 (include/callireader_hip.h)."""
+        B.check(B.lib.cr_enable_fp8_decode(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_decode')
+
     # ---- vision ----
     def _chk_pixels(self, px):
         if px.dim() != 4:
@@ -256,6 +261,29 @@ def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torc
     Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
     B.check(B.lib.cr_op_gemm(epi | (kernel << 8), _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')
+    return Cc
+
+
+def op_quantize_fp8(Wt):
+    """rows of a bf16 [N, K] matrix -> (uint8 e4m3 [N, K], fp32 scale [N]) exactly as cr_enable_fp8_decode builds them"""
+    N, K = Wt.shape
+    q = torch.empty(N, K, device=Wt.device, dtype=torch.uint8)
+    sc = torch.empty(N, device=Wt.device, dtype=torch.float32)
+    B.check(B.lib.cr_op_quantize_fp8(_p(Wt), Wt.stride(0), N, K, _p(q), _p(sc), _stream()), 'cr_op_quantize_fp8')
+    return q, sc
+
+
+def op_gemm_fp8(epi, A, q, sc, res=None, out_dtype=torch.bfloat16):
+    """cr_op_gemm with e4m3 weights `q` [N, K] and row scales `sc` (decode kernel, M <= 64)."""
+    M, K = A.shape
+    N = q.shape[0]
+    ncols = N // 2 if epi == 4 else N
+    mrows = M
+    if epi == 7:
+        mrows, out_dtype = 8 * M, torch.float32
+    Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
+    B.check(B.lib.cr_op_gemm(epi | (1 << 16), _p(A), A.stride(0), _p(q), q.stride(0), _p(Cc), Cc.stride(0), _p(None), _p(sc),
+                             _p(res), res.stride(0) if res is not None else 0, M, N, K, 0, _stream()), 'cr_op_gemm(fp8)')
     return Cc
 
 

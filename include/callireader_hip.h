@@ -25,10 +25,10 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 3   /* 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream */
+#define CR_ABI_VERSION 3   /* 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
-enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3 };
+enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
 
 typedef struct cr_ctx cr_ctx;
 typedef struct cr_kv cr_kv;
@@ -141,6 +141,15 @@ int cr_llm_prefill_batch(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, con
 int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int64_t* force_tokens, float penalty,
                   float* logits, void* stream);
 
+/* fp8 weight path (BASELINE.json configs[4]; the reference itself has no fp8 -- an option, OFF by default, the headline stays
+ * bf16).  enable != 0: every linear weight of the language model the batched decode streams (wqkv, wo, w1|w3, w2 of each
+ * layer, the LM head) gets an e4m3 (OCP e4m3fn) copy with one fp32 scale per output row, scale = max|w| / 448, built on the
+ * device on first use; cr_llm_decode with <= 64 sequences then reads those (half the HBM bytes), dequantising in registers
+ * (exact: e4m3 is a subset of bf16), multiplying in the same bf16 MFMA with fp32 accumulation and applying the row scale to
+ * the fp32 sum.  Activations, KV cache, prefill and everything visual stay bf16.  enable == 0 switches back (copies kept).
+ * Call after cr_finalize; re-run it after reloading weights. */
+int cr_enable_fp8_decode(cr_ctx* ctx, int enable, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* While enabled, every launch of the dense-GEMM kernel made by the stage entry points is bracketed by a pair of
  * HIP events on the launch stream.  cr_profile_read synchronises and returns, for the compute-bound class
@@ -172,6 +181,9 @@ int cr_orderformer(cr_ctx* ctx, const void* boxes, int B, int L, float* scores, 
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
                void* stream);
+/* With bit 16 of epi set, W is e4m3 bytes [N][ldw] and `scale` is float[N] (one per row): C = epi((A . W^T) * scale); M <= 64. */
+/* rows of a bf16 matrix -> e4m3 bytes q [N][K] + scale [N] (max|w| / 448 per row), as cr_enable_fp8_decode builds them */
+int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float* scale, void* stream);
 int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* beta, int64_t rows, int n, float eps,
                     int pixel_shuffle, void* stream);
 int cr_op_rmsnorm(const void* in, void* out, const void* gamma, int64_t rows, int n, float eps, void* stream);
