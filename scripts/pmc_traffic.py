@@ -3,7 +3,7 @@
 memory-side traffic of the dominant kernel class, as MI355X_MICROARCH.md "HBM" prescribes:
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      (gfx950 reports half the bytes of wide coalesced reads; units KB)
 Note: these counters sit on the L2's fabric side, so Infinity-Cache hits are included.
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> ["bench arguments of the two runs"]"""
 import csv, glob, json, sys
 
 def load(d, counter):
@@ -28,6 +28,7 @@ for fam in fetch:
     fb, wb = 2 * sum(fetch[fam]) * 1024, sum(write.get(fam, [0])) * 1024
     out[fam] = {'launches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / max(len(write.get(fam, [1])), 1),
                 'traffic_bytes_per_launch': fb / n + wb / max(len(write.get(fam, [1])), 1)}
-out['_how'] = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) of: python3 bench.py --steps 1 --warmup 0 --pages 8 --new-tokens 4 --no-cpu-baseline --no-vit-extra; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024'
+args = sys.argv[4] if len(sys.argv) > 4 else '--steps 1 --warmup 0 --pages 8 --new-tokens 4 --no-cpu-baseline --no-vit-extra'
+out['_how'] = f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) of: python3 bench.py {args}; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024'
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))
