@@ -22,7 +22,8 @@ for (N, K) in [(4096, 1024), (1024, 4096), (3072, 1024), (1024, 1024)]:
     scale = (torch.rand(N, device='cuda', generator=g) * 0.1).bfloat16()
     res = (torch.rand(M, N, device='cuda', generator=g)).bfloat16()
     fl = 2.0 * M * N * K
-    run(f'N={N} K={K} store nobias', lambda: E.op_gemm(0, A, W), fl)
-    run(f'N={N} K={K} store bias', lambda: E.op_gemm(0, A, W, bias=bias), fl)
-    run(f'N={N} K={K} gelu bias', lambda: E.op_gemm(1, A, W, bias=bias), fl)
-    run(f'N={N} K={K} ls_res bias', lambda: E.op_gemm(2, A, W, bias=bias, scale=scale, res=res), fl)
+    for kern in [int(x) for x in os.environ.get('KERNS', '2').split(',')]:
+        run(f'k{kern} N={N} K={K} store nobias', lambda: E.op_gemm(0, A, W, kernel=kern), fl)
+        run(f'k{kern} N={N} K={K} store bias', lambda: E.op_gemm(0, A, W, bias=bias, kernel=kern), fl)
+        run(f'k{kern} N={N} K={K} gelu bias', lambda: E.op_gemm(1, A, W, bias=bias, kernel=kern), fl)
+        run(f'k{kern} N={N} K={K} ls_res bias', lambda: E.op_gemm(2, A, W, bias=bias, scale=scale, res=res, kernel=kern), fl)

@@ -68,9 +68,9 @@ def engine():
     from callireader_amd.engine import Engine
     dims = ModelDims.full()
     torch.set_num_threads(min(32, os.cpu_count() or 8))
-    eng = Engine(dims, max_pos=1024)
+    eng = Engine(dims, max_pos=4096)
     t0 = time.time()
-    for parts in (('vit', 'mlp1'), ('llm',)):
+    for parts in (('vit', 'mlp1'), ('resampler', 'vq'), ('llm',)):
         for k, v in synthetic.iter_state_dict(dims, parts=parts, seed=0):     # CPU draw == the golden script's weights
             eng.load_weight(k, v)
     eng.load_rope()
@@ -229,6 +229,81 @@ def test_llm_extra_prompts_token_agreement(gold, engine):
     RESULTS['llm32_extra'] = summary
     _dump()
     print('full-depth LLM, extra prompts:', json.dumps(summary))
+
+
+def test_config1_example_page_end_to_end_vs_reference(gold, engine):
+    """BASELINE config 1 at full depth on the reference's own example page (tests/golden/config1_full_depth.npz, written by
+    scripts/make_golden_config1.py through the reference's modules): 11 page tiles + 96 character tiles -> ViT 24L + mlp1 ->
+    PerceiverResampler -> cosine VQ -> denormalised pseudo tokens -> the 3 158-id prompt of the reference's tokenizer with
+    both masked overwrites -> InternLM2 32L prefill + 15 greedy steps, teacher-forced along the reference's ids."""
+    from PIL import Image
+    from callireader_amd import preprocess
+    g1 = np.load(os.path.join(ROOT, 'tests', 'golden', 'config1_full_depth.npz'))
+    g, _ = gold
+    noise_vit, noise_llm = float(g['vit24.ref_bf16_vs_fp32_rel_l2']), float(g['llm32.ref_bf16_vs_fp32_rel_l2'])
+    img = Image.open(os.path.join(ROOT, 'tests', 'golden', 'example0.jpg')).convert('RGB')
+    boxes = preprocess.boxes_from_labelme(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'example0_boxes.json'))))
+    page_px = preprocess.load_image(img).to(torch.bfloat16)
+    arr = np.array(img)
+    char_px = torch.cat([preprocess.load_image_2(Image.fromarray(arr[y1:y2, x1:x2])).to(torch.bfloat16) for x1, y1, x2, y2 in boxes])
+    assert page_px.shape[0] == 11 and char_px.shape[0] == 96
+
+    feat_page = engine.extract_feature(page_px.cuda())
+    feat_chars = engine.extract_feature(char_px.cuda())
+    rs = engine.resample(feat_chars)
+    idx = engine.vq(rs)
+    back = engine.denorm(rs, idx)
+    torch.cuda.synchronize()
+    out = {}
+    for name, t in (('feat_page', feat_page), ('feat_chars', feat_chars), ('resampler', rs), ('pseudo', back)):
+        ref = torch.from_numpy(g1[f'{name}.sample'])
+        assert int(g1[f'{name}.numel']) == t.numel(), name
+        got = subsample(t.cpu(), int(g1[f'{name}.step']), ref.numel())
+        out[name] = {'rel_l2': rel_l2(got, ref), 'max_abs': float((got - ref).abs().max()), 'ref_max_abs': float(ref.abs().max())}
+    ref_idx = torch.from_numpy(g1['vq.indices'])
+    gap = torch.from_numpy(g1['vq.top2_cos'])
+    gap = (gap[..., 0] - gap[..., 1]).reshape(-1)
+    neq = (idx.cpu().reshape(-1) != ref_idx.reshape(-1))
+    out['vq'] = {'rows': int(neq.numel()), 'equal': int((~neq).sum()), 'reference_top2_gap_min': float(gap.min()),
+                 'largest_reference_gap_where_different': float(gap[neq].max()) if neq.any() else 0.0}
+
+    ids = torch.from_numpy(g1['input_ids'])
+    assert int((ids == 92546).sum()) == 11 * 256 and int((ids == 92537).sum()) == back.numel() // 4096
+    emb = engine.embed_splice(ids, vit_embeds=feat_page, ref_embeds=back)
+    ref_ids, margins = g1['greedy_tokens'].tolist(), g1['top2_margin'].tolist()
+    top_ids, top_val = torch.from_numpy(g1['top16_ids']), torch.from_numpy(g1['top16_logits'])
+    strided = bits_to_f32(g1['logits_stride8_bf16_bits'])
+    steps = len(ref_ids) - 1
+    kv = engine.kv_alloc(1, 3328)
+    lg = engine.prefill(kv, 0, emb, want_logits=True)
+    rows = []
+    for t in range(steps + 1):
+        got = lg.float().cpu().reshape(-1)
+        picked = kv.generated(0)[t]
+        rows.append({'rel_l2_stride8': rel_l2(got[::8], strided[t]), 'max_abs_stride8': float((got[::8] - strided[t]).abs().max()),
+                     'max_abs_top16': float((got[top_ids[t]] - top_val[t]).abs().max()), 'ref_id': ref_ids[t], 'hip_id': picked,
+                     'ref_margin': margins[t]})
+        if t < steps:
+            lg = engine.decode(kv, [0], force_tokens=torch.tensor([ref_ids[t]]), want_logits=True)
+    torch.cuda.synchronize()
+    kv.free()
+    out['llm'] = {'prompt_tokens': int(ids.numel()), 'steps': steps, 'picks_equal': sum(r['ref_id'] == r['hip_id'] for r in rows), 'picks': len(rows),
+                  'worst_rel_l2': max(r['rel_l2_stride8'] for r in rows), 'worst_max_abs': max(r['max_abs_stride8'] for r in rows),
+                  'differing': [{'step': t, **r} for t, r in enumerate(rows) if r['ref_id'] != r['hip_id']]}
+    RESULTS['config1_example_page'] = out
+    _dump()
+    print('config 1, full depth:', json.dumps(out))
+    for name in ('feat_page', 'feat_chars'):
+        assert out[name]['rel_l2'] <= noise_vit, (name, out[name])
+    # the resampler adds 4 bf16 layers on top of the visual features; the pseudo tokens are its output times sigma plus mu
+    assert out['resampler']['rel_l2'] <= 2 * noise_vit and out['pseudo']['rel_l2'] <= 2 * noise_vit, out
+    # VQ: equal, or the reference's own best two cosines sit within 4 bf16 steps of each other (0.002 at cos ~ 0.07)
+    assert out['vq']['largest_reference_gap_where_different'] <= 0.002, out['vq']
+    for t, r in enumerate(rows):
+        assert r['rel_l2_stride8'] <= noise_llm, (t, r)
+        if r['ref_id'] != r['hip_id']:
+            print(f'  config 1 step {t}: pick differs, reference margin {r["ref_margin"]:.4f}, |d| on this row {r["max_abs_stride8"]:.4f}')
+            assert r['ref_margin'] <= 2 * max(r['max_abs_stride8'], r['max_abs_top16']), (t, r)
 
 
 def test_vit_config2_properties(engine):
