@@ -201,7 +201,7 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     p.bias = (const bf16*)bias; p.scale = (const bf16*)scale; p.res = (const bf16*)res; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K; p.group = group;
     const int kern = (epi >> 8) & 0xff;           // tests pin a kernel: 1 = 128x128, 2 = 256x256, 3 = skinny
-    p.kernel = kern == 1 ? 128 : kern == 2 ? 256 : kern == 3 ? 1 : kern == 4 ? 2 : 0;
+    p.kernel = kern == 1 ? 128 : kern == 2 ? 256 : kern == 3 ? 1 : 0;
     if (epi & (1 << 16)) { p.w8 = 1; p.wscale = (const float*)scale; p.scale = nullptr; }      // e4m3 weights + per-row fp32 scales
     epi &= 0xff;
     int r = launch_gemm(epi, p, (hipStream_t)stream);

@@ -135,7 +135,6 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 
 bool gemm256_supported(int epi, const GemmParams& p);
 int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream);
-int launch_gemm2w(int epi, const GemmParams& p, hipStream_t stream);
 bool gemm_skinny_supported(int epi, const GemmParams& p);
 int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream);
 
@@ -148,7 +147,6 @@ int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     const int force = p.kernel ? p.kernel : env_force;
     if (force == 1) return gemm_skinny_supported(epi, p) ? launch_gemm_skinny(epi, p, stream) : CR_ERR_ARG;
     if (force == 256) return (p.K % 128) == 0 ? launch_gemm256(epi, p, stream) : CR_ERR_ARG;
-    if (force == 2) return launch_gemm2w(epi, p, stream);
     if (force != 128) {
         if (gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
         if (gemm256_supported(epi, p)) return launch_gemm256(epi, p, stream);           // large M: persistent 256x256 kernel

@@ -51,8 +51,7 @@ def test_gemm_exact_integers(E, M, N, K):
 
 @pytest.mark.parametrize('M,N,K', [(2049, 520, 128), (2304, 768, 256), (4100, 1024, 640), (2048, 512, 1024), (5000, 300 * 3, 384),
                                    (8300, 2304, 1024), (2100, 520, 4096), (16500, 1280, 256)])
-@pytest.mark.parametrize('kern', [2, 4])
-def test_gemm256_exact_integers(E, M, N, K, kern):
+def test_gemm256_exact_integers(E, M, N, K):
     """The 256x256 8-phase kernel, pinned (the dispatcher's cost model would hand several of these shapes to the
     128x128 kernel): exact integer data checks the unit/sub-tile/swizzle maps, the K-tile pairing (K = 128 is a single
     pair), ragged M/N edges, long K loops on data that misses L2, and workgroups that walk several tiles (> 256 tiles:
@@ -65,21 +64,20 @@ def test_gemm256_exact_integers(E, M, N, K, kern):
     A[:, K - 1] = ((torch.arange(M) // 7) % 2).float()
     ref = rb(A @ W.t())                                       # integers: the fp32 accumulator is exact, one bf16 rounding
     Ad, Wd = bf(A).to(dev()), bf(W).to(dev())
-    outs = [E.op_gemm(0, Ad, Wd, kernel=kern) for _ in range(6)]   # repeated launches: a staging race shows as a flaky tile
+    outs = [E.op_gemm(0, Ad, Wd, kernel=2) for _ in range(6)]   # repeated launches: a staging race shows as a flaky tile
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o.float().cpu(), ref)
 
 
-@pytest.mark.parametrize('kern', [2, 4])
-def test_gemm256_random_is_deterministic_and_close(E, kern):
+def test_gemm256_random_is_deterministic_and_close(E):
     g = torch.Generator().manual_seed(77)
     M, N, K = 8200, 1024, 4096
     A = bf(_rand((M, K), g)).to(dev())
     W = bf(_rand((N, K), g, 0.02)).to(dev())
     bias = bf(_rand((N,), g, 0.1)).to(dev())
     ref = rb(A.float() @ W.float().t() + bias.float())
-    outs = [E.op_gemm(0, A, W, bias=bias, kernel=kern) for _ in range(5)]
+    outs = [E.op_gemm(0, A, W, bias=bias, kernel=2) for _ in range(5)]
     torch.cuda.synchronize()
     torch.testing.assert_close(outs[0].float(), ref, rtol=RTOL, atol=2e-2)
     for o in outs[1:]:
@@ -90,8 +88,7 @@ def _rand(shape, g, scale=1.0):
     return (torch.randn(shape, generator=g) * scale)
 
 
-@pytest.mark.parametrize('M,N,K,kern', [(515, 384, 256, 1), (2050, 1024, 1024, 1), (2050, 1024, 1024, 2), (515, 384, 256, 2),
-                                        (2050, 1024, 1024, 4), (515, 384, 128, 4), (70000, 256, 64, 4)])
+@pytest.mark.parametrize('M,N,K,kern', [(515, 384, 256, 1), (2050, 1024, 1024, 1), (2050, 1024, 1024, 2), (515, 384, 256, 2)])
 def test_gemm_epilogues(E, M, N, K, kern):
     g = torch.Generator().manual_seed(1)
     A = bf(_rand((M, K), g)).to(dev())
@@ -131,9 +128,8 @@ def test_gemm_epilogue_rounding_is_bit_exact(E):
     _bit_exact_epilogues(E, g, M, N, K, 1)
 
 
-@pytest.mark.parametrize('kern', [2, 4])
-def test_gemm256_epilogue_rounding_is_bit_exact(E, kern):
-    _bit_exact_epilogues(E, torch.Generator().manual_seed(13), 2100, 512, 128, kern)
+def test_gemm256_epilogue_rounding_is_bit_exact(E):
+    _bit_exact_epilogues(E, torch.Generator().manual_seed(13), 2100, 512, 128, 2)
 
 
 def _bit_exact_epilogues(E, g, M, N, K, kern):
@@ -160,7 +156,7 @@ def _bit_exact_epilogues(E, g, M, N, K, kern):
     torch.testing.assert_close(out.float().cpu(), rb(torch.nn.functional.gelu(lin)), rtol=2 ** -7, atol=1e-6)
 
 
-@pytest.mark.parametrize('kern', [1, 2, 4])
+@pytest.mark.parametrize('kern', [1, 2])
 def test_gelu_epilogue_on_every_bf16_input(E, kern):
     """The GELU epilogue's input is always a bf16 value, so its whole domain is 65 k points: push every normal bf16
     below 1e30 through the epilogue (A = [x, 0, ...], W = e_0: the accumulator IS x) and compare with torch's CPU GELU
@@ -191,7 +187,7 @@ def test_gelu_epilogue_on_every_bf16_input(E, kern):
     assert float(((got.float() - ref.float()).abs() / x.abs())[far].max() if far.any() else 0) <= 2.0 ** -22
 
 
-@pytest.mark.parametrize('M,kern', [(300, 1), (2100, 2), (2100, 4)])
+@pytest.mark.parametrize('M,kern', [(300, 1), (2100, 2)])
 def test_gemm_swiglu(E, M, kern):
     g = torch.Generator().manual_seed(2)
     F, K = 512, 256
@@ -209,7 +205,7 @@ def test_gemm_swiglu(E, M, kern):
     torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=2e-2)
 
 
-@pytest.mark.parametrize('kern', [1, 2, 4])
+@pytest.mark.parametrize('kern', [1, 2])
 def test_gemm_patch_rows(E, kern):
     g = torch.Generator().manual_seed(3)
     T, G, N, K = 2, 1024, 256, 128
@@ -226,9 +222,8 @@ def test_gemm_patch_rows(E, kern):
     assert torch.equal(got[:, 0], torch.zeros(T, N, device=dev()))      # CLS rows are not this kernel's
 
 
-@pytest.mark.parametrize('kern', [2, 4])
 @pytest.mark.parametrize('epi', [0, 3, 6])
-def test_gemm256_ragged_n(E, epi, kern):
+def test_gemm256_ragged_n(E, epi):
     """256x256 kernel on an N that is no multiple of 4 (the vocabulary is 92 553): the last column block takes the
     element-wise epilogue, bias / residual / fp32 output included."""
     g = torch.Generator().manual_seed(40 + epi)
@@ -239,13 +234,13 @@ def test_gemm256_ragged_n(E, epi, kern):
     res = bf(_rand((M, N), g)).to(dev())
     lin = rb(A.float() @ W.float().t() + bias.float())
     if epi == 6:
-        out = E.op_gemm(6, A, W, bias=bias, out_dtype=torch.float32, kernel=kern)
+        out = E.op_gemm(6, A, W, bias=bias, out_dtype=torch.float32, kernel=2)
         ref = lin
     elif epi == 3:
-        out = E.op_gemm(3, A, W, bias=bias, res=res, kernel=kern).float()
+        out = E.op_gemm(3, A, W, bias=bias, res=res, kernel=2).float()
         ref = rb(res.float() + lin)
     else:
-        out = E.op_gemm(0, A, W, bias=bias, kernel=kern).float()
+        out = E.op_gemm(0, A, W, bias=bias, kernel=2).float()
         ref = lin
     torch.cuda.synchronize()
     torch.testing.assert_close(out, ref, rtol=RTOL, atol=2e-2)
@@ -345,8 +340,7 @@ def test_gemm_skinny_k_sliced_partials(E, M, N, K):
     torch.testing.assert_close(total, A.float() @ W.float().t(), rtol=1e-4, atol=2e-3)
 
 
-@pytest.mark.parametrize('M,N,K,kern', [(300, 1000, 128, 1), (2304, 1000, 128, 2), (2100, 4100, 256, 2), (70, 130, 64, 1),
-                                        (2304, 1000, 128, 4), (2100, 4100, 256, 4)])
+@pytest.mark.parametrize('M,N,K,kern', [(300, 1000, 128, 1), (2304, 1000, 128, 2), (2100, 4100, 256, 2), (70, 130, 64, 1)])
 def test_gemm_row_argmax_partials(E, M, N, K, kern):
     """EPI_ARGMAX (cosine VQ, models/similarity.py:19-21): per row and 64-column block the first maximum of bf16(A.W^T).
     Small-integer data make the products exact and full of ties, so the first-index rule is what is being tested;
