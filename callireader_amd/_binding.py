@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ModelDesc(C.Structure):
@@ -52,6 +52,7 @@ SIGNATURES = {
     'cr_llm_prefill_batch': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, C.POINTER(C.c_int32), f32, vp, vp]),
     'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, f32, vp, vp]),
     'cr_enable_fp8_decode': (i32, [vp, i32, vp]),
+    'cr_enable_fp8_mfma': (i32, [vp, i32, vp]),
     'cr_op_quantize_fp8': (i32, [vp, i64, i32, i32, vp, vp, vp]),
     'cr_profile': (i32, [vp, i32]),
     'cr_profile_read': (i32, [vp, C.POINTER(C.c_double)]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     'cr_op_gemm': (i32, [i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     'cr_op_layernorm': (i32, [vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     'cr_op_rmsnorm': (i32, [vp, vp, vp, i64, i32, f32, vp]),
+    'cr_op_norm_fp8': (i32, [vp, vp, vp, i64, i32, f32, vp, vp, vp]),
     'cr_op_attention': (i32, [vp, vp, vp, vp, C.POINTER(i64), i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]),
 }
 

@@ -99,7 +99,7 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
         hipEventRecord(rec.b, st);
         const double n_out = epi == EPI_SWIGLU ? p.N / 2.0 : p.N;
         rec.flops = 2.0 * p.M * (double)p.N * p.K;
-        rec.bytes = (p.w8 ? 1.0 : 2.0) * (double)p.N * p.K + 2.0 * (double)p.M * p.K + (epi == EPI_ARGMAX ? 8.0 * p.M * ((p.N + 63) / 64) : (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out);
+        rec.bytes = (p.w8 ? 1.0 : 2.0) * (double)p.N * p.K + (p.a8 ? 1.0 : 2.0) * (double)p.M * p.K + (p.a8 ? 4.0 * (p.M + p.N) : 0.0) + (epi == EPI_ARGMAX ? 8.0 * p.M * ((p.N + 63) / 64) : (epi == EPI_F32 ? 4.0 : 2.0) * p.M * n_out);
         rec.big = p.M >= 1024;
         c->prof_recs.push_back(rec);
         c->prof_issued++;
@@ -203,6 +203,7 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     const int kern = (epi >> 8) & 0xff;           // tests pin a kernel: 1 = 128x128, 2 = 256x256, 3 = skinny
     p.kernel = kern == 1 ? 128 : kern == 2 ? 256 : kern == 3 ? 1 : 0;
     if (epi & (1 << 16)) { p.w8 = 1; p.wscale = (const float*)scale; p.scale = nullptr; }      // e4m3 weights + per-row fp32 scales
+    if (epi & (1 << 17)) { p.a8 = 1; p.ascale = (const float*)res; p.res = nullptr; }          // e4m3 activations too: `res` = fp32 row scales [M]
     epi &= 0xff;
     int r = launch_gemm(epi, p, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_gemm(epi=%d, M=%d, N=%d, K=%d) rejected or failed to launch", epi, M, N, K);
@@ -216,6 +217,17 @@ int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* be
     p.gamma = (const bf16*)gamma; p.beta = (const bf16*)beta; p.rows = rows; p.eps = eps;
     int r = launch_layernorm(p, n, pixel_shuffle ? 1 : 0, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_layernorm(rows=%lld, n=%d) rejected or failed", (long long)rows, n);
+    return CR_OK;
+}
+
+int cr_op_norm_fp8(const void* in, const void* gamma, const void* beta, int64_t rows, int n, float eps, void* out8, float* out_scale,
+                   void* stream) {
+    if (!in || !gamma || !out8 || !out_scale) return cr_fail(CR_ERR_ARG, "cr_op_norm_fp8: null argument");
+    NormParams p{};
+    p.in = (const bf16*)in; p.ld_in = n; p.out = nullptr; p.ld_out = n; p.gamma = (const bf16*)gamma; p.beta = (const bf16*)beta;
+    p.rows = rows; p.eps = eps; p.out8 = (unsigned char*)out8; p.out8_scale = out_scale;
+    const int r = beta ? launch_layernorm(p, n, 0, (hipStream_t)stream) : launch_rmsnorm(p, n, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_norm_fp8(rows=%lld, n=%d) rejected or failed", (long long)rows, n);
     return CR_OK;
 }
 

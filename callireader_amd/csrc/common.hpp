@@ -87,6 +87,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float erf_abs = 1.0f - s * e;
     return (x * 0.5f) * (1.0f + copysignf(erf_abs, x));
 }
+// 16 fp32 values times `inv` -> 16 e4m3 bytes (OCP e4m3fn, round to nearest even, saturating): one 16-byte store
+__device__ __forceinline__ void store16_e4m3(unsigned char* dst, const float* y, float inv) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+    u32x4_ w = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned d = 0;
+        d = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * q] * inv, y[4 * q + 1] * inv, d, false);
+        d = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * q + 2] * inv, y[4 * q + 3] * inv, d, true);
+        w[q] = d;
+    }
+    *(u32x4_*)dst = w;
+}
+
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -128,6 +142,10 @@ struct GemmParams {
     // fp8 weight streaming (decode, M <= 64 only): W points at e4m3 bytes [N][ldw], wscale[n] restores row n (C = (X . W8^T) * wscale)
     int w8;
     const float* wscale;
+    // fp8 matrix-core path (gemm256 only, M large): A points at e4m3 bytes [M][lda] as well (w8 set too), K counts fp8 elements
+    // (K % 256 == 0), ascale[m] restores row m: C = epi((A8 . W8^T) * ascale[m] * wscale[n] + bias)
+    int a8;
+    const float* ascale;
 };
 
 // EPI_ARGMAX partial of one row and one 64-column block: the bf16-rounded maximum (as fp32 bits, high word) and its column

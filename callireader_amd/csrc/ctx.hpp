@@ -27,6 +27,7 @@ struct cr_ctx {
                                         // null stream (which cannot be captured); implicitly ordered with it
     uint64_t weight_gen = 0;            // bumped by cr_load_weight / cr_finalize: captured graphs hold weight pointers
     bool fp8_decode = false;            // cr_enable_fp8_decode: batched decode streams e4m3 copies of the LLM's linear weights (half the bytes)
+    bool fp8_mfma = false;              // cr_enable_fp8_mfma: the norm-fed linears of the ViT, the projector and the LLM prefill run e4m3 x e4m3 on the matrix cores
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
     std::unordered_map<std::string, DevTensor> w;
     // workspace
@@ -43,6 +44,12 @@ struct cr_ctx {
     double prof_acc[2][4] = {};         // [tiled M >= 1024 | the rest][launches, ms, flops, bytes] of the retired records
     int64_t prof_issued = 0, prof_retired = 0, prof_lost = 0, prof_peak_pending = 0;
 };
+
+// e4m3 copy + per-row fp32 scale of weight `name` as "fp8.<name>" / "fp8s.<name>" (llm.hip); a no-op when already built for this shape
+int build_fp8_copy(cr_ctx* c, const std::string& name, int k_multiple, hipStream_t st);
+// C = epi((A8 . W8^T) * ascale[m] * wscale[n] + bias): both operands e4m3 (gemm256's F8 instance)
+int ctx_gemm_f8(cr_ctx* c, int epi, const void* a8, const float* ascale, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc,
+                const bf16* bias, int M, int N, int K, hipStream_t st);
 
 // GEMM launch used by every stage: validates, launches, and (when profiling) brackets the launch with events.
 int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st);

@@ -135,12 +135,14 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 
 bool gemm256_supported(int epi, const GemmParams& p);
 int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream);
+int launch_gemm256_f8(int epi, const GemmParams& p, hipStream_t stream);
 bool gemm_skinny_supported(int epi, const GemmParams& p);
 int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream);
 
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return CR_ERR_ARG;
     if ((p.lda & 7) || (p.ldw & 7)) return CR_ERR_ARG;
+    if (p.a8) return launch_gemm256_f8(epi, p, stream);                                                  // e4m3 x e4m3 on the matrix cores
     if (p.w8) return gemm_skinny_supported(epi, p) ? launch_gemm_skinny(epi, p, stream) : CR_ERR_ARG;   // fp8 weights: decode kernel only
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.C & 15)) return CR_ERR_ARG;
     static const int env_force = [] { const char* e = getenv("CR_GEMM_FORCE"); return e ? atoi(e) : 0; }();   // tuning aid: 128 | 256

@@ -88,13 +88,17 @@ constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per 
 //   slice image: row r at r*128 B; the 8-byte slot s of a row sits at (s ^ r): the 16 lanes of a ds_write_b64 group
 //   (rows 0..15, same s) hit 16 different bank pairs, and the 16-byte read-back chunk c = (slot pair) is found at
 //   c ^ (r >> 1) with its halves exchanged when r is odd.
-template <int EPI>
+template <int EPI, bool F8 = false>
 __device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&bias_f)[4][4], const float (&scale_f)[4][4],
-                                            bool has_bias, char* buf, int lane) {
+                                            bool has_bias, char* buf, int lane, const float (&dq_f)[4][4], float dq_row) {
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         float x[4] = {a[j][0], a[j][1], a[j][2], a[j][3]};
+        if (F8) {                                             // e4m3 operands: the sum of products times the row's and the column's scale
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] *= dq_row * dq_f[j][e];
+        }
         if (has_bias) {
 #pragma unroll
             for (int e = 0; e < 4; e++) x[e] += bias_f[j][e];
@@ -119,14 +123,23 @@ __device__ __forceinline__ bf16x8 read_chunk(const char* buf, int r, int c) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[8][4], char* stg, int row_base, int col0,
                                               int lane) {
     constexpr bool ADD_ROWS = (EPI == EPI_LS_RES || EPI == EPI_RES);
     const bool has_bias = p.bias != nullptr;
     const bool full_n = col0 + 64 <= p.N;
     // ---- per-column operands in the accumulator layout
-    float bias_f[4][4], scale_f[4][4];
+    float bias_f[4][4], scale_f[4][4], dq_f[4][4];
+    if (F8) {                                                 // column (weight-row) scales; N % 64 == 0 on this path
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4 w = *(const f32x4*)(p.wscale + min(col0 + j * 16 + (lane >> 4) * 4, p.N - 4));
+#pragma unroll
+            for (int e = 0; e < 4; e++) dq_f[j][e] = w[e];
+        }
+    }
+    auto dq_row = [&](int mf) { return F8 ? p.ascale[min(row_base + mf * 16 + (lane & 15), p.M - 1)] : 1.0f; };
     {
         const bool vec = full_n && ((((uintptr_t)p.bias) | ((uintptr_t)p.scale)) & 7) == 0;
 #pragma unroll
@@ -187,7 +200,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
 #pragma unroll
         for (int mf = 0; mf < 8; mf++) {
             char* buf = stg + (mf & 1) * 2048;
-            stage_slice<EPI>(acc[mf], bias_f, scale_f, has_bias, buf, lane);
+            stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf));
             __builtin_amdgcn_wave_barrier();
             const int gm = row_base + mf * 16 + r;
             const bf16x8 gt = read_chunk(buf, r, 2 * oc), up = read_chunk(buf, r, 2 * oc + 1);
@@ -218,7 +231,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
 #pragma unroll
     for (int mf = 0; mf < 8; mf++) {
         char* buf = stg + (mf & 1) * 2048;
-        stage_slice<EPI>(acc[mf], bias_f, scale_f, has_bias, buf, lane);
+        stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf));
         __builtin_amdgcn_wave_barrier();
         if (PRE && vec_ok && mf + 1 < 8) load_rows(mf + 1, rnext);
 #pragma unroll
@@ -257,7 +270,23 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
     }
 }
 
-template <int EPI>
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// F8 fragments live in the 8-register operand tuples of v_mfma_scale_f32_16x16x128_f8f6f4 from the start: the ds_read_b128 of
+// sub-tile ksub lands in registers 4*ksub .. 4*ksub+3.  A lane's 32 k are thus the 16 of its ksub-0 chunk followed by the 16
+// of its ksub-1 chunk -- the same k for both operands, which is all a dot product needs.
+__device__ __forceinline__ i32x8 f8_put(const i32x8& v, int ks, const bf16x8& frag) {
+    const i32x4 x = __builtin_bit_cast(i32x4, frag);
+    const i32x8 w = __builtin_shufflevector(x, x, 0, 1, 2, 3, 0, 1, 2, 3);
+    return ks == 0 ? __builtin_shufflevector(w, v, 0, 1, 2, 3, 12, 13, 14, 15) : __builtin_shufflevector(v, w, 0, 1, 2, 3, 8, 9, 10, 11);
+}
+
+// F8: both operands are e4m3 bytes.  The byte images in memory and in LDS, the DMA, the fragment reads and the schedule are
+// those of the bf16 kernel on a matrix of K / 2 "bf16 columns" (the launcher halves K and the leading dimensions); a K-tile
+// of 128 bytes per row is 128 k instead of 64, and a matrix slot issues 8 v_mfma_scale_f32_16x16x128_f8f6f4 (unit block
+// scales, 32 cycles each) where the bf16 kernel issues 16 v_mfma_f32_16x16x32_bf16 (16 cycles each): the same slot length at
+// twice the k.  The per-row / per-column fp32 scales are applied to the finished sum in the epilogue.
+template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -319,13 +348,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     f32x4 acc[8][4];
     bf16x8 ra[4][2];          // A fragments of the current quadrant row: [i][ksub]
     bf16x8 rb[2][2][2];       // B fragments: [nh][j][ksub]
+    i32x8 ra8[4] = {};        // F8: the same fragments as 32-byte operands [i], [nh][j]
+    i32x8 rb8[2][2] = {};
 
 #define READ_A(buf, unit)                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
-        ra[i][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + a_sub + (i * 2 + ks) * 1024);
+        { const bf16x8 f_ = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + a_sub + (i * 2 + ks) * 1024); \
+          if (F8) ra8[i] = f8_put(ra8[i], ks, f_); else ra[i][ks] = f_; }
 #define READ_B(buf, unit, nh)                                                                   \
     _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++) \
-        rb[nh][j][ks] = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024);
+        { const bf16x8 f_ = *(const bf16x8*)(smem + (buf) * KBUF + (unit) * UNIT + b_sub + (j * 2 + ks) * 1024); \
+          if (F8) rb8[nh][j] = f8_put(rb8[nh][j], ks, f_); else rb[nh][j][ks] = f_; }
     // a phase = a memory slot (fragment reads of this phase, one unit's two DMA pieces, the counted wait) and a
     // matrix slot (16 MFMAs), each closed by s_barrier.  Waves 4..7 run one slot behind waves 0..3, so on every
     // SIMD one wave's matrix slot runs beside its partner's memory slot.
@@ -339,9 +372,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     WAIT_LGKM0();                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_setprio(1);                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int i = 0; i < 4; i++) \
-        _Pragma("unroll") for (int j = 0; j < 2; j++)                                           \
-            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[nh][j][ks], ra[i][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
+    if (F8) {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) \
+            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(  \
+                rb8[nh][j], ra8[i], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0, 0, 0, 0); \
+    } else {                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int i = 0; i < 4; i++) \
+            _Pragma("unroll") for (int j = 0; j < 2; j++)                                       \
+                acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[nh][j][ks], ra[i][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
+    }                                                                                           \
     __builtin_amdgcn_s_setprio(0);                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_barrier();
@@ -408,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #endif       // the look-ahead (K-tile 0 and U0, U1 of K-tile 1 of the next tile) has landed: slots 1..4 rely on it
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----
-        epilogue_tile<EPI>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
+        epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
 #ifdef CR_DIAG_STAMPS
         if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -419,13 +458,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     WAIT_VM0();       // dead re-loads of the final pair must land before the workgroup releases its LDS
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
     static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)gemm256_kernel<EPI>, LDS_BYTES2)) return CR_ERR_HIP;
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm256_kernel<EPI, F8>, LDS_BYTES2)) return CR_ERR_HIP;
     const int n_cu = cr_device_cus();
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
@@ -441,6 +480,22 @@ bool gemm256_supported(int epi, const GemmParams& p) {
     const double c256 = (double)((t256 + 255) / 256);
     const double c128 = 0.75 * (double)((t128 + 511) / 512);
     return c256 <= c128;
+}
+
+// e4m3 x e4m3 on the matrix cores: the bf16 kernel's byte view of the operands (two fp8 per "bf16 column")
+int launch_gemm256_f8(int epi, const GemmParams& p8, hipStream_t stream) {
+    if (!p8.a8 || !p8.w8 || !p8.ascale || !p8.wscale || (p8.K % 256) != 0 || (p8.N % 64) != 0 || (p8.lda & 15) || (p8.ldw & 15) ||
+        (((uintptr_t)p8.A | (uintptr_t)p8.W | (uintptr_t)p8.wscale) & 15))
+        return CR_ERR_ARG;
+    GemmParams p = p8;
+    p.K = p8.K / 2; p.lda = p8.lda / 2; p.ldw = p8.ldw / 2;
+    switch (epi) {
+        case EPI_STORE: return launch_t<EPI_STORE, true>(p, stream);
+        case EPI_GELU: return launch_t<EPI_GELU, true>(p, stream);
+        case EPI_SWIGLU: return launch_t<EPI_SWIGLU, true>(p, stream);
+        case EPI_F32: return launch_t<EPI_F32, true>(p, stream);
+    }
+    return CR_ERR_ARG;
 }
 
 int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream) {

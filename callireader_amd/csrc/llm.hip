@@ -258,9 +258,10 @@ int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t
     return ctx_gemm(c, epi, p, st);
 }
 
-int rms(const bf16* in, int64_t ld_in, bf16* out, const bf16* w, int64_t rows, float eps, hipStream_t st) {
+int rms(const bf16* in, int64_t ld_in, bf16* out, const bf16* w, int64_t rows, float eps, hipStream_t st, float* row_scale = nullptr) {
     NormParams np{};
     np.in = in; np.ld_in = ld_in; np.out = out; np.ld_out = D; np.gamma = w; np.rows = rows; np.eps = eps;
+    if (row_scale) { np.out8 = (unsigned char*)out; np.out8_scale = row_scale; }     // e4m3 rows in the first half of `out`
     return launch_rmsnorm(np, D, st);
 }
 
@@ -305,6 +306,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
     bf16* q = ar.take<bf16>((size_t)M * D);
     bf16* ao = ar.take<bf16>((size_t)M * D);
     bf16* act = ar.take<bf16>((size_t)M * ff);
+    float* hs = ar.take<float>((size_t)M);          // fp8 matrix-core path: one scale per normalised row
     const bf16 *cosT = W(c, "rope.cos"), *sinT = W(c, "rope.sin");
     if (!cosT || !sinT) return CR_ERR_STATE;
     const int64_t per_layer = (int64_t)kv->n_seqs * NKV * kv->max_tokens * HD;
@@ -321,9 +323,12 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         CR_TRY(layer_weights(c, l, w));
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
-        if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st));
+        // prefill on the fp8 matrix-core path: both norms emit e4m3 rows + scales, wqkv and w1|w3 take them (gemm256 F8)
+        const bool m8 = !decode && c->fp8_mfma && M >= 256 && w.q_qkv && w.s_qkv && w.q_13 && w.s_13;
+        if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         const bool f8 = decode && M <= 64 && c->fp8_decode && w.q_qkv && w.s_qkv && w.q_o && w.s_o && w.q_13 && w.s_13 && w.q_2 && w.s_2;
-        if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st)
+        if (m8) CR_TRY(ctx_gemm_f8(c, EPI_STORE, h, hs, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, M, QKV, D, st));
+        else if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st)
                                : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st));
         else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st)
                         : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
@@ -358,10 +363,11 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         } else {
             CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st)
                       : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
-            CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st));
+            CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         }
-        CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st)
-                  : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
+        if (m8) CR_TRY(ctx_gemm_f8(c, EPI_SWIGLU, h, hs, w.q_13, w.s_13, act, ff, nullptr, M, 2 * ff, D, st));
+        else CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st)
+                       : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
         if (sliced) {
             CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, act, ff, w.q_2, w.s_2, pbuf, D, nullptr, 0, M, D, ff, st)
                       : gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st));
@@ -384,10 +390,39 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
 size_t layers_ws(cr_ctx* c, int M, int nsplit = 0) {
     const size_t ff = (size_t)WT(c, "derived.w13.0")->shape[0] / 2;
     const size_t sliced = nsplit > 0 && M <= 64 ? (size_t)8 * QKV * M * 4 : 0;       // K-slice partial sums of the decode GEMMs
-    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + 8192;
+    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + (size_t)M * 4 + 8192;
 }
 
 }  // namespace
+
+int build_fp8_copy(cr_ctx* c, const std::string& nm, int k_multiple, hipStream_t st) {
+    const DevTensor* src = WT(c, nm);
+    if (!src) return CR_ERR_STATE;
+    const int64_t N = src->shape[0], K = src->shape[1];
+    if ((K % k_multiple) != 0) return cr_fail(CR_ERR_ARG, "fp8 copy: %s has K = %lld, not a multiple of %d", nm.c_str(), (long long)K, k_multiple);
+    auto have = c->w.find("fp8." + nm);
+    if (have != c->w.end() && have->second.shape == src->shape && c->w.count("fp8s." + nm)) return CR_OK;     // built already for these weights
+    DevTensor q, s;
+    q.dtype = CR_U8; q.shape = src->shape; q.bytes = (size_t)N * K;
+    s.dtype = CR_F32; s.shape = {N}; s.bytes = (size_t)N * 4;
+    if (hipMalloc(&q.ptr, q.bytes) != hipSuccess || hipMalloc(&s.ptr, s.bytes) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "fp8 copy: %s", nm.c_str());
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, st, (const bf16*)src->ptr, K, (int)K, (unsigned char*)q.ptr, (float*)s.ptr);
+    for (const char* pre : {"fp8.", "fp8s."}) {
+        auto old = c->w.find(pre + nm);
+        if (old != c->w.end()) { hipFree(old->second.ptr); c->w.erase(old); }
+    }
+    c->w["fp8." + nm] = q;
+    c->w["fp8s." + nm] = s;
+    return CR_OK;
+}
+
+int ctx_gemm_f8(cr_ctx* c, int epi, const void* a8, const float* ascale, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc,
+                const bf16* bias, int M, int N, int K, hipStream_t st) {
+    GemmParams p{};
+    p.A = (const bf16*)a8; p.lda = K; p.W = (const bf16*)w8->ptr; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
+    p.w8 = 1; p.wscale = (const float*)ws->ptr; p.a8 = 1; p.ascale = ascale;
+    return ctx_gemm(c, epi, p, st);
+}
 
 int llm_finalize(cr_ctx* c, hipStream_t st) {
     for (int l = 0; l < c->d.llm_layers; l++) {
@@ -425,6 +460,31 @@ int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float*
     return CR_OK;
 }
 
+int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
+    if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_mfma: null context");
+    if (!enable) { c->fp8_mfma = false; return CR_OK; }
+    if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: call cr_finalize first");
+    CR_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<std::string> names;
+    // the linears whose input is a norm's output: that kernel emits the e4m3 row and its scale for free
+    for (int l = 0; l < c->d.vit_layers; l++) {
+        const std::string p = "vision_model.encoder.layers." + std::to_string(l) + ".";
+        if (c->w.count(p + "attn.qkv.weight")) { names.push_back(p + "attn.qkv.weight"); names.push_back(p + "mlp.fc1.weight"); }
+    }
+    if (c->w.count("mlp1.1.weight")) names.push_back("mlp1.1.weight");
+    for (int l = 0; l < c->d.llm_layers; l++) {
+        const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
+        if (c->w.count(p + "attention.wqkv.weight")) { names.push_back(p + "attention.wqkv.weight"); names.push_back("derived.w13." + std::to_string(l)); }
+    }
+    for (const std::string& nm : names) CR_TRY(build_fp8_copy(c, nm, 256, st));
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipStreamSynchronize(st));
+    c->fp8_mfma = true;
+    c->weight_gen++;
+    return CR_OK;
+}
+
 int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: null context");
     if (!enable) { c->fp8_decode = false; return CR_OK; }
@@ -438,26 +498,7 @@ int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
         names.push_back("derived.w13." + std::to_string(l)); names.push_back(p + "feed_forward.w2.weight");
     }
     names.push_back("language_model.output.weight");
-    for (const std::string& nm : names) {
-        const DevTensor* src = WT(c, nm);
-        if (!src) return CR_ERR_STATE;
-        const int64_t N = src->shape[0], K = src->shape[1];
-        if ((K % 512) != 0) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: %s has K = %lld, not a multiple of 512", nm.c_str(), (long long)K);
-        auto have = c->w.find("fp8." + nm);
-        if (have != c->w.end() && have->second.shape == src->shape && c->w.count("fp8s." + nm)) continue;     // built already for these weights
-        DevTensor q, s;
-        q.dtype = CR_U8; q.shape = src->shape; q.bytes = (size_t)N * K;
-        s.dtype = CR_F32; s.shape = {N}; s.bytes = (size_t)N * 4;
-        if (hipMalloc(&q.ptr, q.bytes) != hipSuccess || hipMalloc(&s.ptr, s.bytes) != hipSuccess)
-            return cr_fail(CR_ERR_NOMEM, "cr_enable_fp8_decode: %s", nm.c_str());
-        hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, st, (const bf16*)src->ptr, K, (int)K, (unsigned char*)q.ptr, (float*)s.ptr);
-        for (const char* pre : {"fp8.", "fp8s."}) {
-            auto old = c->w.find(pre + nm);
-            if (old != c->w.end()) { hipFree(old->second.ptr); c->w.erase(old); }
-        }
-        c->w["fp8." + nm] = q;
-        c->w["fp8s." + nm] = s;
-    }
+    for (const std::string& nm : names) CR_TRY(build_fp8_copy(c, nm, 512, st));
     CR_HIP(hipGetLastError());
     CR_HIP(hipStreamSynchronize(st));
     c->fp8_decode = true;

@@ -35,6 +35,29 @@ __device__ __forceinline__ float row_sum(float v, float* red, int tid) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+template <int TPR>
+__device__ __forceinline__ float row_max(float v, float* red, int tid) {
+    v = wave_max(v);
+    if (TPR == 64) return v;
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// the normalised row as e4m3 + one scale (NormParams::out8): y is rounded to bf16 first, as the bf16 path stores it
+template <int TPR>
+__device__ __forceinline__ void store_row_e4m3(const NormParams& p, int64_t orow, int t, float* y, float* red, int tid, bool live) {
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { y[e] = rbf(y[e]); mx = fmaxf(mx, fabsf(y[e])); }
+    mx = row_max<TPR>(mx, red, tid);
+    const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
+    if (!live) return;
+    store16_e4m3(p.out8 + orow * (16 * TPR) + t * 16, y, 1.0f / sc);
+    if (t == 0) p.out8_scale[orow] = sc;
+}
+
 template <int TPR, int MODE>   // MODE 0: plain rows, 1: pixel-shuffle gather (N = 4096 from [T,1025,1024])
 __global__ __launch_bounds__(256) void layernorm_kernel(const NormParams p) {
     __shared__ float red[4];
@@ -74,7 +97,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const NormParams p) {
     if (live) {
         int64_t orow = row;
         if (p.out_group > 0) orow = (row / p.in_group) * p.out_group + p.out_off + row % p.in_group;
-        store16(p.out + orow * p.ld_out + t * 16, y);
+        if (!p.out8) store16(p.out + orow * p.ld_out + t * 16, y);
+    }
+    if (p.out8) {                                             // uniform branch: every thread of the row takes part in the maximum
+        int64_t orow = r;
+        if (p.out_group > 0) orow = (r / p.in_group) * p.out_group + p.out_off + r % p.in_group;
+        store_row_e4m3<TPR>(p, orow, t, y, red, tid, live);
     }
 }
 
@@ -93,7 +121,8 @@ __global__ __launch_bounds__(256) void rmsnorm4096_kernel(const NormParams p) {
     load16(p.gamma + tid * 16, g);
 #pragma unroll
     for (int e = 0; e < 16; e++) y[e] = g[e] * rbf(x[e] * rs);
-    store16(p.out + row * p.ld_out + tid * 16, y);
+    if (p.out8) store_row_e4m3<256>(p, row, tid, y, red, tid, true);
+    else store16(p.out + row * p.ld_out + tid * 16, y);
 }
 
 // residual add of a K-sliced GEMM result + the next RMSNorm (decode): modeling_internlm2.py:655-669

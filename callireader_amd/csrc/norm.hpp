@@ -10,6 +10,10 @@ struct NormParams {
     float eps;
     // optional output row regrouping: out_row = (row / in_group) * out_group + out_off + row % in_group
     int in_group, out_group, out_off;
+    // fp8 matrix-core path: when out8 is set the row leaves as e4m3 bytes out8[row][n] (leading dimension n) with one fp32
+    // scale per row, out8_scale[row] = max|y| / 448 over the bf16-rounded normalised row y (1 for an all-zero row), q = RNE(y / scale);
+    // `out` is then not written (the normalised row only feeds the next GEMM)
+    unsigned char* out8; float* out8_scale;
 };
 
 // mode 0: rows of n (1024 | 4096) bf16; mode 1: pixel-shuffle gather feeding mlp1's LayerNorm (n = 4096)

@@ -37,6 +37,11 @@ int vit_finalize(cr_ctx* c, hipStream_t st) {
     return CR_OK;
 }
 
+static const DevTensor* WTopt(cr_ctx* c, const std::string& name) {
+    auto it = c->w.find(name);
+    return it == c->w.end() ? nullptr : &it->second;
+}
+
 static int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
                 const bf16* scale, const bf16* res, int64_t ldr, int M, int N, int K, int group, hipStream_t st) {
     GemmParams p{};
@@ -52,6 +57,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
     bf16* h = ar.take<bf16>((size_t)M * C1);       // LN output, later attention output
     bf16* qkv = ar.take<bf16>((size_t)M * C3);
     bf16* f = ar.take<bf16>((size_t)M * FF);
+    float* hs = ar.take<float>((size_t)M);          // fp8 matrix-core path: one scale per LayerNorm row
 
     const bf16* patch_w = W(c, "derived.patch_w");
     const bf16* patch_b = W(c, "vision_model.embeddings.patch_embedding.bias");
@@ -76,11 +82,17 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         if (!n1w || !n1b || !n2w || !n2b || !qkvw || !qkvb || !pw || !pb || !f1w || !f1b || !f2w || !f2b || !ls1 || !ls2)
             return CR_ERR_STATE;
 
+        // cr_enable_fp8_mfma: the two LayerNorms emit e4m3 rows + scales (into h) and QKV / fc1 multiply e4m3 x e4m3
+        const DevTensor *q_qkv = WTopt(c, "fp8." + p + "attn.qkv.weight"), *s_qkv = WTopt(c, "fp8s." + p + "attn.qkv.weight");
+        const DevTensor *q_f1 = WTopt(c, "fp8." + p + "mlp.fc1.weight"), *s_f1 = WTopt(c, "fp8s." + p + "mlp.fc1.weight");
+        const bool m8 = c->fp8_mfma && q_qkv && s_qkv && q_f1 && s_f1;
         NormParams np{};
         np.in = x; np.ld_in = C1; np.out = h; np.ld_out = C1; np.rows = M; np.eps = c->d.vit_ln_eps;
         np.gamma = n1w; np.beta = n1b;
+        if (m8) { np.out8 = (unsigned char*)h; np.out8_scale = hs; }
         CR_TRY(launch_layernorm(np, C1, 0, st));
-        CR_TRY(gemm(c, EPI_STORE, h, C1, qkvw, C1, qkv, C3, qkvb, nullptr, nullptr, 0, M, C3, C1, 0, st));
+        if (m8) CR_TRY(ctx_gemm_f8(c, EPI_STORE, h, hs, q_qkv, s_qkv, qkv, C3, qkvb, M, C3, C1, st));
+        else CR_TRY(gemm(c, EPI_STORE, h, C1, qkvw, C1, qkv, C3, qkvb, nullptr, nullptr, 0, M, C3, C1, 0, st));
 
         AttnParams ap{};
         ap.Q = qkv; ap.K = qkv + C1; ap.V = qkv + 2 * C1; ap.O = h;
@@ -93,7 +105,8 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
 
         np.gamma = n2w; np.beta = n2b;
         CR_TRY(launch_layernorm(np, C1, 0, st));
-        CR_TRY(gemm(c, EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
+        if (m8) CR_TRY(ctx_gemm_f8(c, EPI_GELU, h, hs, q_f1, s_f1, f, FF, f1b, M, FF, C1, st));
+        else CR_TRY(gemm(c, EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
         CR_TRY(gemm(c, EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
     }
     return CR_OK;
@@ -101,8 +114,10 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
 
 static size_t vit_ws_bytes(int T) {
     const size_t M = (size_t)T * TOK;
-    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + 4096;
+    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + M * 4 + 8192;
 }
+
+static size_t project_ws_bytes(int T) { return (size_t)T * 256 * 4096 * 4 + (size_t)T * 256 * 4 + 8192; }   // a, b, row scales
 
 static int project_chunk(cr_ctx* c, const bf16* vit_out, int T, bf16* out, hipStream_t st) {
     const int M = T * 256;
@@ -113,10 +128,15 @@ static int project_chunk(cr_ctx* c, const bf16* vit_out, int T, bf16* out, hipSt
     const bf16 *w1 = W(c, "mlp1.1.weight"), *b1 = W(c, "mlp1.1.bias");
     const bf16 *w3 = W(c, "mlp1.3.weight"), *b3 = W(c, "mlp1.3.bias");
     if (!lw || !lb || !w1 || !b1 || !w3 || !b3) return CR_ERR_STATE;
+    const DevTensor *q_w1 = WTopt(c, "fp8.mlp1.1.weight"), *s_w1 = WTopt(c, "fp8s.mlp1.1.weight");
+    const bool m8 = c->fp8_mfma && q_w1 && s_w1;
+    float* as = ar.take<float>((size_t)M);
     NormParams np{};
     np.in = vit_out; np.out = a; np.ld_out = 4096; np.rows = M; np.eps = 1e-5f; np.gamma = lw; np.beta = lb;
+    if (m8) { np.out8 = (unsigned char*)a; np.out8_scale = as; }
     CR_TRY(launch_layernorm(np, 4096, 1, st));     // drop CLS + pixel_shuffle folded into the load
-    CR_TRY(gemm(c, EPI_GELU, a, 4096, w1, 4096, b, 4096, b1, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
+    if (m8) CR_TRY(ctx_gemm_f8(c, EPI_GELU, a, as, q_w1, s_w1, b, 4096, b1, M, 4096, 4096, st));
+    else CR_TRY(gemm(c, EPI_GELU, a, 4096, w1, 4096, b, 4096, b1, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
     CR_TRY(gemm(c, EPI_STORE, b, 4096, w3, 4096, out, 4096, b3, nullptr, nullptr, 0, M, 4096, 4096, 0, st));
     return CR_OK;
 }
@@ -141,7 +161,7 @@ int cr_project(cr_ctx* c, const void* vit_out, int T, void* out, void* stream) {
     if (!c || !vit_out || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_project: bad argument");
     CR_HIP(hipSetDevice(c->device));
     const int CH = 256;
-    CR_TRY(ws_ensure(c, (size_t)(T < CH ? T : CH) * 256 * 4096 * 2 * 2 + 4096));
+    CR_TRY(ws_ensure(c, project_ws_bytes(T < CH ? T : CH)));
     for (int t0 = 0; t0 < T; t0 += CH) {
         const int tc = (T - t0) < CH ? (T - t0) : CH;
         CR_TRY(project_chunk(c, (const bf16*)vit_out + (size_t)t0 * TOK * C1, tc, (bf16*)out + (size_t)t0 * 256 * 4096,
@@ -157,7 +177,7 @@ int cr_extract_feature(cr_ctx* c, const void* pixels, int T, void* out, void* st
     // ViT output of a chunk sits at the top of the workspace, below it the per-chunk scratch of both stages.
     for (int t0 = 0; t0 < T;) {
         const int tc = next_chunk(T - t0);
-        const size_t inner = vit_ws_bytes(tc) > (size_t)tc * 256 * 4096 * 4 + 4096 ? vit_ws_bytes(tc) : (size_t)tc * 256 * 4096 * 4 + 4096;
+        const size_t inner = vit_ws_bytes(tc) > project_ws_bytes(tc) ? vit_ws_bytes(tc) : project_ws_bytes(tc);
         const size_t xbytes = (size_t)tc * TOK * C1 * 2;
         CR_TRY(ws_ensure(c, inner + 256 + xbytes));
         bf16* x = (bf16*)(c->ws + ((inner + 255) & ~(size_t)255));

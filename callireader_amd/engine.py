@@ -87,6 +87,11 @@ class Engine:
         B.check(B.lib.cr_enable_fp8_decode(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_decode')
 
     # ---- vision ----
+    def enable_fp8_mfma(self, on=True):
+        """cr_enable_fp8_mfma: norm-fed linears (ViT QKV / fc1, mlp1[1], LLM prefill wqkv / w1|w3) multiply e4m3 x e4m3 on the matrix
+        cores; OFF by default (the reference's arithmetic is bf16)."""
+        B.check(B.lib.cr_enable_fp8_mfma(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_mfma')
+
     def _chk_pixels(self, px):
         if px.dim() != 4:
             raise ValueError(f'wrong pixel_values size: {px.shape}')       # modeling_intern_vit.py:417-420
@@ -285,6 +290,26 @@ def op_gemm_fp8(epi, A, q, sc, res=None, out_dtype=torch.bfloat16):
     B.check(B.lib.cr_op_gemm(epi | (1 << 16), _p(A), A.stride(0), _p(q), q.stride(0), _p(Cc), Cc.stride(0), _p(None), _p(sc),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, 0, _stream()), 'cr_op_gemm(fp8)')
     return Cc
+
+
+def op_gemm_fp8x8(epi, a8, a_scale, q, sc, bias=None, out_dtype=torch.bfloat16):
+    """cr_op_gemm with e4m3 activations `a8` [M, K] + row scales and e4m3 weights `q` [N, K] + row scales: the 256x256 kernel's
+    v_mfma_f32_16x16x128_f8f6f4 instance (epi 0 | 1 | 4 | 6)."""
+    M, K = a8.shape
+    N = q.shape[0]
+    Cc = torch.zeros(M, N // 2 if epi == 4 else N, device=a8.device, dtype=out_dtype)
+    B.check(B.lib.cr_op_gemm(epi | (1 << 16) | (1 << 17), _p(a8), a8.stride(0), _p(q), q.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(sc),
+                             _p(a_scale), 0, M, N, K, 0, _stream()), 'cr_op_gemm(fp8 x fp8)')
+    return Cc
+
+
+def op_norm_fp8(x, gamma, beta, eps):
+    """LayerNorm (beta given) or RMSNorm (beta None) of bf16 rows -> (uint8 e4m3 [rows, n], fp32 scale [rows])"""
+    rows, n = x.shape
+    q = torch.empty(rows, n, device=x.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    B.check(B.lib.cr_op_norm_fp8(_p(x), _p(gamma), _p(beta), rows, n, float(eps), _p(q), _p(sc), _stream()), 'cr_op_norm_fp8')
+    return q, sc
 
 
 def op_layernorm(x, gamma, beta, eps, pixel_shuffle=False):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 3   /* 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 4   /* 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -149,6 +149,14 @@ int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int6
  * the fp32 sum.  Activations, KV cache, prefill and everything visual stay bf16.  enable == 0 switches back (copies kept).
  * Call after cr_finalize; re-run it after reloading weights. */
 int cr_enable_fp8_decode(cr_ctx* ctx, int enable, void* stream);
+/* fp8 on the matrix cores (same standing: an option, OFF by default).  enable != 0: the linears whose input is a norm's output --
+ * QKV and fc1 of every ViT layer, mlp1's first linear, wqkv and w1|w3 of every LLM layer in PREFILL -- get the e4m3 copy + row
+ * scale above, the norm kernel in front of each writes the normalised row as e4m3 with one fp32 scale per row
+ * (max|y| / 448 over the bf16-rounded row) instead of bf16, and the 256x256 tiled kernel multiplies e4m3 x e4m3 with
+ * v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulation, twice the bf16 rate), applying ascale[m] * wscale[n] to the finished sum before the
+ * bias and the rest of the epilogue.  proj / fc2 / wo / w2, attention, the residual stream, the KV cache and decode stay as they
+ * are.  Call after cr_finalize; re-run it after reloading weights. */
+int cr_enable_fp8_mfma(cr_ctx* ctx, int enable, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* While enabled, every launch of the dense-GEMM kernel made by the stage entry points is bracketed by a pair of
@@ -182,11 +190,17 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, 
                const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
                void* stream);
 /* With bit 16 of epi set, W is e4m3 bytes [N][ldw] and `scale` is float[N] (one per row): C = epi((A . W^T) * scale); M <= 64. */
+/* With bits 16 AND 17 set, A is e4m3 bytes [M][lda] too and `res` is float[M] (one scale per row of A):
+ * C = epi((A . W^T) * res[m] * scale[n] + bias); the 256x256 kernel's e4m3 instance: K % 256 == 0, N % 64 == 0, epi 0 | 1 | 4 | 6. */
 /* rows of a bf16 matrix -> e4m3 bytes q [N][K] + scale [N] (max|w| / 448 per row), as cr_enable_fp8_decode builds them */
 int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float* scale, void* stream);
 int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* beta, int64_t rows, int n, float eps,
                     int pixel_shuffle, void* stream);
 int cr_op_rmsnorm(const void* in, void* out, const void* gamma, int64_t rows, int n, float eps, void* stream);
+/* the same norms with the fp8 output cr_enable_fp8_mfma uses: beta == NULL selects RMSNorm (n = 4096), otherwise LayerNorm
+ * (n = 1024 | 4096); out8 = e4m3 [rows][n], out_scale = float[rows] */
+int cr_op_norm_fp8(const void* in, const void* gamma, const void* beta, int64_t rows, int n, float eps, void* out8, float* out_scale,
+                   void* stream);
 /* q/k/v/o addressed as base + b*bs + row*rs + head*hs (elements) */
 int cr_op_attention(const void* q, const void* k, const void* v, void* o, const int64_t* strides12, int B, int H,
                     int Sq, int Sk, int head_dim, int kv_group, int causal, int q_pos0, float q_prescale, float s_div,
