@@ -49,7 +49,7 @@ struct cr_ctx {
 int build_fp8_copy(cr_ctx* c, const std::string& name, int k_multiple, hipStream_t st);
 // C = epi((A8 . W8^T) * ascale[m] * wscale[n] + bias): both operands e4m3 (gemm256's F8 instance)
 int ctx_gemm_f8(cr_ctx* c, int epi, const void* a8, const float* ascale, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc,
-                const bf16* bias, int M, int N, int K, hipStream_t st);
+                const bf16* bias, int M, int N, int K, hipStream_t st, const bf16* res = nullptr, int64_t ldr = 0);
 
 // GEMM launch used by every stage: validates, launches, and (when profiling) brackets the launch with events.
 int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st);

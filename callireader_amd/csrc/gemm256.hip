@@ -492,6 +492,7 @@ int launch_gemm256_f8(int epi, const GemmParams& p8, hipStream_t stream) {
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE, true>(p, stream);
         case EPI_GELU: return launch_t<EPI_GELU, true>(p, stream);
+        case EPI_RES: return p.res ? launch_t<EPI_RES, true>(p, stream) : CR_ERR_ARG;
         case EPI_SWIGLU: return launch_t<EPI_SWIGLU, true>(p, stream);
         case EPI_F32: return launch_t<EPI_F32, true>(p, stream);
     }

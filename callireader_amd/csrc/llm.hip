@@ -307,6 +307,8 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
     bf16* ao = ar.take<bf16>((size_t)M * D);
     bf16* act = ar.take<bf16>((size_t)M * ff);
     float* hs = ar.take<float>((size_t)M);          // fp8 matrix-core path: one scale per normalised row
+    const bool any8 = !decode && c->fp8_mfma && M >= 256;
+    unsigned char* a8 = any8 ? ar.take<unsigned char>((size_t)M * ff) : nullptr;     // e4m3 rows of the attention output / the SwiGLU output
     const bf16 *cosT = W(c, "rope.cos"), *sinT = W(c, "rope.sin");
     if (!cosT || !sinT) return CR_ERR_STATE;
     const int64_t per_layer = (int64_t)kv->n_seqs * NKV * kv->max_tokens * HD;
@@ -324,7 +326,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
         // prefill on the fp8 matrix-core path: both norms emit e4m3 rows + scales, wqkv and w1|w3 take them (gemm256 F8)
-        const bool m8 = !decode && c->fp8_mfma && M >= 256 && w.q_qkv && w.s_qkv && w.q_13 && w.s_13;
+        const bool m8 = any8 && w.q_qkv && w.s_qkv && w.q_13 && w.s_13 && w.q_o && w.s_o && w.q_2 && w.s_2;
         if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         const bool f8 = decode && M <= 64 && c->fp8_decode && w.q_qkv && w.s_qkv && w.q_o && w.s_o && w.q_13 && w.s_13 && w.q_2 && w.s_2;
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_STORE, h, hs, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, M, QKV, D, st));
@@ -361,8 +363,13 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                       : gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st));
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_o, M, w.fn, h, c->d.rms_eps, st));
         } else {
-            CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st)
-                      : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+            if (m8) {       // wo and w2 take activations no norm produced: one quantiser pass each (row maximum, then the e4m3 row)
+                hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, ao, (int64_t)D, D, a8, hs);
+                CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_o, w.s_o, x, D, nullptr, M, D, D, st, x, D));
+            } else {
+                CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st)
+                          : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+            }
             CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         }
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_SWIGLU, h, hs, w.q_13, w.s_13, act, ff, nullptr, M, 2 * ff, D, st));
@@ -378,6 +385,9 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                 next_norm = wn.an;
             }
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_2, M, next_norm, h, c->d.rms_eps, st));
+        } else if (m8) {
+            hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, act, (int64_t)ff, ff, a8, hs);
+            CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_2, w.s_2, x, D, nullptr, M, D, ff, st, x, D));
         } else {
             CR_TRY(f8 ? gemm8(c, EPI_RES, act, ff, w.q_2, w.s_2, x, D, x, D, M, D, ff, st)
                       : gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
@@ -390,7 +400,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
 size_t layers_ws(cr_ctx* c, int M, int nsplit = 0) {
     const size_t ff = (size_t)WT(c, "derived.w13.0")->shape[0] / 2;
     const size_t sliced = nsplit > 0 && M <= 64 ? (size_t)8 * QKV * M * 4 : 0;       // K-slice partial sums of the decode GEMMs
-    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + (size_t)M * 4 + 8192;
+    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + (size_t)M * 4 + (size_t)M * ff + 8192;
 }
 
 }  // namespace
@@ -417,8 +427,9 @@ int build_fp8_copy(cr_ctx* c, const std::string& nm, int k_multiple, hipStream_t
 }
 
 int ctx_gemm_f8(cr_ctx* c, int epi, const void* a8, const float* ascale, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc,
-                const bf16* bias, int M, int N, int K, hipStream_t st) {
+                const bf16* bias, int M, int N, int K, hipStream_t st, const bf16* res, int64_t ldr) {
     GemmParams p{};
+    p.res = res; p.ldr = ldr;
     p.A = (const bf16*)a8; p.lda = K; p.W = (const bf16*)w8->ptr; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
     p.w8 = 1; p.wscale = (const float*)ws->ptr; p.a8 = 1; p.ascale = ascale;
     return ctx_gemm(c, epi, p, st);
@@ -475,7 +486,10 @@ int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     if (c->w.count("mlp1.1.weight")) names.push_back("mlp1.1.weight");
     for (int l = 0; l < c->d.llm_layers; l++) {
         const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
-        if (c->w.count(p + "attention.wqkv.weight")) { names.push_back(p + "attention.wqkv.weight"); names.push_back("derived.w13." + std::to_string(l)); }
+        if (c->w.count(p + "attention.wqkv.weight")) {
+            names.push_back(p + "attention.wqkv.weight"); names.push_back("derived.w13." + std::to_string(l));
+            names.push_back(p + "attention.wo.weight"); names.push_back(p + "feed_forward.w2.weight");     // their inputs take a quantiser pass
+        }
     }
     for (const std::string& nm : names) CR_TRY(build_fp8_copy(c, nm, 256, st));
     CR_HIP(hipGetLastError());
