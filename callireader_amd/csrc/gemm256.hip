@@ -323,6 +323,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     uint32_t qB[2];           // [nh]
     auto make_ptrs = [&](int m0, int n0) {
         // sub-tiles 2*wave and 2*wave + 1 are the two k-halves (ksub 0 / 1) of the same 16 rows
+        int srow = lane >> 2, schunk = (lane & 3) ^ ((srow >> 3) << 1);
+        if (F8) {                                             // the e4m3 instance has no register to keep these across a tile: derive them again
+            int l = tid;
+            asm volatile("" : "+v"(l));
+            l &= 63;
+            srow = l >> 2; schunk = (l & 3) ^ ((srow >> 3) << 1);
+        }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int arow = m0 + (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + srow;
@@ -341,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
     const int lrow = lane & 15;
     const int lane_off = lrow * 64 + (((lane >> 4) ^ ((lrow >> 3) << 1)) * 16);
-    const int a_sub = wm * 8 * 1024 + lane_off;          // + (i*2 + ksub) * 1024
-    const int b_sub = wn * 4 * 1024 + lane_off;          // + (j*2 + ksub) * 1024
+    int a_sub = wm * 8 * 1024 + lane_off;                // + (i*2 + ksub) * 1024
+    int b_sub = wn * 4 * 1024 + lane_off;                // + (j*2 + ksub) * 1024
     char* stg = smem + LDS_MAIN2 + wave * 4096;       // epilogue: two 2 KiB bf16 slices per wave
 
     f32x4 acc[8][4];
@@ -397,6 +404,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_s_barrier();
 
     while (true) {
+        if (F8) {           // not kept across the epilogue (no register to spare there: a spilled copy would drain vmcnt at the tile's start)
+            int l = tid;
+            asm volatile("" : "+v"(l));
+            const int r16 = l & 15, off = r16 * 64 + ((((l & 63) >> 4) ^ ((r16 >> 3) << 1)) * 16);
+            a_sub = wm * 8 * 1024 + off;
+            b_sub = wn * 4 * 1024 + off;
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
