@@ -138,6 +138,8 @@ int launch_gemm256(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm256_f8(int epi, const GemmParams& p, hipStream_t stream);
 bool gemm_skinny_supported(int epi, const GemmParams& p);
 int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream);
+bool gemm_tail_supported(int epi, const GemmParams& p);
+int launch_gemm_tail(int epi, const GemmParams& p, hipStream_t stream);
 
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return CR_ERR_ARG;
@@ -151,7 +153,30 @@ int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (force == 256) return (p.K % 128) == 0 ? launch_gemm256(epi, p, stream) : CR_ERR_ARG;
     if (force != 128) {
         if (gemm_skinny_supported(epi, p)) return launch_gemm_skinny(epi, p, stream);   // decode: stream W once from HBM
-        if (gemm256_supported(epi, p)) return launch_gemm256(epi, p, stream);           // large M: persistent 256x256 kernel
+        if (gemm256_supported(epi, p)) {                                                // large M: persistent 256x256 kernel
+            // A few rows past a multiple of 256 can cost a whole extra round of tiles (BASELINE config 2: 32 tiles = 128 x 256 + 32
+            // rows; with N = 1024 that is 2 rounds + 4 tiles = 3 rounds).  When cutting them off saves a round, they go through a
+            // one-wave-per-workgroup kernel (<= 64 rows, gemm_skinny.hip: launch_gemm_tail) or the 128x128 kernel instead, whose K order
+            // and rounding are the same (a row's result does not depend on the kernel:
+            // tests/test_gpu_full_depth.py chunking test, tests/test_gpu_ops.py::test_gemm_tail_rows_take_the_small_kernel).
+            const int r = p.M % 256, cus = cr_device_cus();
+            const long ntn = (p.N + 255) / 256, tm = p.M / 256;
+            if (r > 0 && tm > 0 && epi != EPI_PATCH && epi != EPI_ARGMAX && (tm * ntn + cus - 1) / cus < ((tm + 1) * ntn + cus - 1) / cus &&
+                (long)((r + 127) / 128) * ((p.N + 127) / 128) <= 2L * cus) {
+                GemmParams a = p, b = p;
+                a.M = p.M - r;
+                b.M = r;
+                b.A = p.A + (int64_t)a.M * p.lda;
+                b.C = (char*)p.C + (int64_t)a.M * p.ldc * (epi == EPI_F32 ? 4 : 2);
+                if (p.res) b.res = p.res + (int64_t)a.M * p.ldr;
+                const int rc = launch_gemm256(epi, a, stream);
+                if (rc != CR_OK) return rc;
+                if (gemm_tail_supported(epi, b)) return launch_gemm_tail(epi, b, stream);
+                b.kernel = 128;
+                return launch_gemm(epi, b, stream);
+            }
+            return launch_gemm256(epi, p, stream);
+        }
     }
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE>(p, stream);

@@ -188,6 +188,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         if (gm >= p.M || gn >= p.N) continue;
         float x = rbf(red[0][t][n][m] + (p.bias ? bf2f(p.bias[gn]) : 0.f));
         if (EPI == EPI_F32) { ((float*)p.C)[(int64_t)gm * p.ldc + gn] = x; continue; }
+        if (EPI == EPI_GELU) x = gelu_erf(x);
+        if (EPI == EPI_LS_RES) x = bf2f(p.res[(int64_t)gm * p.ldr + gn]) + rbf(x * bf2f(p.scale[gn]));
         if (EPI == EPI_RES) x = bf2f(p.res[(int64_t)gm * p.ldr + gn]) + x;
         ((bf16*)p.C)[(int64_t)gm * p.ldc + gn] = f2bf(x);
     }
@@ -259,6 +261,31 @@ PartialGeom partial_geom(int N, int K) {
 }
 
 }  // namespace
+
+// The last M % 256 rows (<= 64) of a tiled GEMM whose 256x256 launch would otherwise pay a whole extra round of tiles for them
+// (gemm.hip: launch_gemm).  ONE wave per workgroup walks the whole K in ascending 32-steps with the same MFMA and the same
+// operand roles as the tiled kernels, so these rows get bit for bit what the tiled kernels would have given them
+// (tests/test_gpu_ops.py::test_gemm_tail_rows_take_the_small_kernel); eight k-steps of loads in flight hide the latency that a
+// lone 128x128 workgroup per 128 columns would expose K / 64 times over.
+bool gemm_tail_supported(int epi, const GemmParams& p) {
+    if (p.M > 64 || p.M <= 0 || p.K % 32 != 0 || p.w8 || p.a8) return false;
+    if (epi == EPI_LS_RES) return p.res && p.scale;
+    if (epi == EPI_RES) return p.res != nullptr;
+    if (epi == EPI_SWIGLU) return p.N % 16 == 0;
+    return epi == EPI_STORE || epi == EPI_GELU || epi == EPI_F32;
+}
+
+int launch_gemm_tail(int epi, const GemmParams& p, hipStream_t stream) {
+    switch (epi) {
+        case EPI_STORE: return launch_mt8<EPI_STORE, 1, 1, false>(p, stream, 1);
+        case EPI_GELU: return launch_mt8<EPI_GELU, 1, 1, false>(p, stream, 1);
+        case EPI_LS_RES: return launch_mt8<EPI_LS_RES, 1, 1, false>(p, stream, 1);
+        case EPI_RES: return launch_mt8<EPI_RES, 1, 1, false>(p, stream, 1);
+        case EPI_SWIGLU: return launch_mt8<EPI_SWIGLU, 1, 1, false>(p, stream, 1);
+        case EPI_F32: return launch_mt8<EPI_F32, 1, 1, false>(p, stream, 1);
+    }
+    return CR_ERR_ARG;
+}
 
 int gemm_partial_splits(int N, int K) { return partial_geom(N, K).splits; }
 

@@ -364,6 +364,26 @@ def test_gemm_row_argmax_partials(E, M, N, K, kern):
         assert torch.equal(col[:, b], am + b * 64), b
 
 
+@pytest.mark.parametrize('M,N,K', [(32800, 1024, 1024), (32800, 1024, 4096), (32800, 3072, 1024), (2100, 512, 256)])
+def test_gemm_tail_rows_take_the_small_kernel(E, M, N, K):
+    """BASELINE config 2 (32 tiles) is 128 x 256 + 32 rows: the dispatcher cuts the 32 rows off the 256x256 launch (they would cost a
+    whole round of tiles) and sends them through the 128x128 kernel.  A row's result must not depend on which kernel made it:
+    random data, every epilogue of the ViT layer, dispatcher's choice against the pinned un-split 256x256 launch, bit for bit."""
+    g = torch.Generator().manual_seed(M + K)
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.03)).to(dev())
+    bias = bf(_rand((N,), g, 0.1)).to(dev())
+    scale = bf(_rand((N,), g, 0.2) + 0.1).to(dev())
+    res = bf(_rand((M, N), g)).to(dev())
+    for epi, kw in ((0, dict(bias=bias)), (1, dict(bias=bias)), (2, dict(bias=bias, scale=scale, res=res)), (3, dict(res=res))):
+        auto = E.op_gemm(epi, A, W, **kw)
+        pinned = E.op_gemm(epi, A, W, kernel=2, **kw)
+        small = E.op_gemm(epi, A[-300:], W, kernel=1, **{k: (v[-300:] if k == 'res' else v) for k, v in kw.items()})
+        torch.cuda.synchronize()
+        assert torch.equal(auto, pinned), epi
+        assert torch.equal(small, pinned[-300:]), epi          # and the 128x128 kernel agrees on rows well inside a 256-row tile too
+
+
 def test_gemm_rejects_bad_k(E):
     A = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
     W = torch.zeros(16, 72, device=dev(), dtype=torch.bfloat16)
