@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ModelDesc(C.Structure):
@@ -51,6 +51,7 @@ SIGNATURES = {
     'cr_llm_prefill': (i32, [vp, vp, i32, vp, i32, f32, vp, vp]),
     'cr_llm_prefill_batch': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, C.POINTER(C.c_int32), f32, vp, vp]),
     'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, f32, vp, vp]),
+    'cr_share_weights': (i32, [vp, vp]),
     'cr_enable_fp8_decode': (i32, [vp, i32, vp]),
     'cr_enable_fp8_mfma': (i32, [vp, i32, vp]),
     'cr_op_quantize_fp8': (i32, [vp, i64, i32, i32, vp, vp, vp]),

@@ -135,13 +135,27 @@ int cr_destroy(cr_ctx* c) {
     if (!c) return CR_OK;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    for (auto& kv : c->w) if (kv.second.ptr) hipFree(kv.second.ptr);
+    if (!c->borrowed) for (auto& kv : c->w) if (kv.second.ptr) hipFree(kv.second.ptr);
     if (c->ws) hipFree(c->ws);
     if (c->scratch) hipFree(c->scratch);
     if (c->side) hipStreamDestroy(c->side);
     for (auto& r : c->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) hipEventDestroy(e);
     delete c;
+    return CR_OK;
+}
+
+int cr_share_weights(cr_ctx* dst, const cr_ctx* src) {
+    if (!dst || !src || dst == src) return cr_fail(CR_ERR_ARG, "cr_share_weights: bad argument");
+    if (dst->device != src->device) return cr_fail(CR_ERR_ARG, "cr_share_weights: contexts on different devices");
+    if (!dst->w.empty() && !dst->borrowed) return cr_fail(CR_ERR_STATE, "cr_share_weights: the destination owns weights of its own");
+    if (!src->finalized) return cr_fail(CR_ERR_STATE, "cr_share_weights: finalize the source first");
+    dst->w = src->w;                    // device pointers only: nothing is copied
+    dst->borrowed = true;
+    dst->d = src->d;
+    dst->finalized = true;
+    dst->fp8_decode = src->fp8_decode; dst->fp8_mfma = src->fp8_mfma;
+    dst->weight_gen++;
     return CR_OK;
 }
 

@@ -38,6 +38,7 @@ inline int cr_device_cus() {
     if (n > 0) return n;
     hipDeviceProp_t prop;
     n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("CR_CUS")) { const int v = atoi(e); if (v > 0 && v <= n) n = v; }     // tuning aid: persistent grids for a CU-masked stream
     cus[dev & 63].store(n, std::memory_order_relaxed);
     return n;
 }

@@ -33,6 +33,7 @@ struct cr_ctx {
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    bool borrowed = false;              // cr_share_weights: the tensors in `w` belong to another context (not freed here)
     // small persistent device scratch (counters, argmax partials)
     char* scratch = nullptr;
     size_t scratch_bytes = 0;

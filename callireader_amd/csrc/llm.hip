@@ -28,6 +28,8 @@ struct cr_kv {
     int32_t* d_ngen;     // [n_seqs] ids generated
     int64_t* d_gen;      // [n_seqs][gen_cap]
     int32_t* d_seqs;     // [n_seqs] staging for the seqs[] of one decode call
+    std::vector<int32_t> seqs_on_device;   // what d_seqs holds (decode skips the host-to-device copy of an unchanged list: a pageable copy
+                                           // makes the host wait for the stream, which stops it from feeding a second stream)
     std::vector<int> len, ngen;
     // batched decode as a hipGraph (CR_DECODE_GRAPH=1): a step is ~290 short launches whose parameters only change with
     // the row count and the number of attention splits (positions, ids and cache lengths live in device memory), so the
@@ -641,6 +643,7 @@ int cr_llm_prefill_batch(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const
         CR_HIP(hipMemcpyAsync(d_row_seq, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: staged before return
     }
     CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    kv->seqs_on_device.assign(seqs, seqs + n);
     CR_HIP(hipMemcpyAsync(x, embeds, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));
     CR_TRY(run_layers(c, kv, x, M, false, segs, d_row_seq, d_row_pos, nullptr, 0, st));
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
@@ -689,7 +692,10 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
     bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
     bf16* hl = x + (size_t)n * D;
     float* lg = (float*)(((uintptr_t)(hl + (size_t)n * D) + 255) & ~(uintptr_t)255);
-    CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));      // every step: prefill uses d_seqs too
+    if ((int)kv->seqs_on_device.size() != n || memcmp(kv->seqs_on_device.data(), seqs, (size_t)n * 4) != 0) {      // prefill uses d_seqs too
+        CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        kv->seqs_on_device.assign(seqs, seqs + n);
+    }
     const bf16* table = W(c, "language_model.model.tok_embeddings.weight");
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!table || !nw || !ow) return CR_ERR_STATE;

@@ -81,6 +81,12 @@ class Engine:
     def finalize(self):
         B.check(B.lib.cr_finalize(self._h, _stream()), 'cr_finalize')
 
+    def share_weights_from(self, other):
+        """cr_share_weights: this (fresh) engine uses `other`'s finalized weights without copying them -- a second host thread can
+        then run stages through it on its own stream while `other` keeps working (PagePipeline).  `other` must outlive it."""
+        B.check(B.lib.cr_share_weights(self._h, other._h), 'cr_share_weights')
+        self._shared_from = other
+
     def enable_fp8_decode(self, on=True):
         """Batched decode streams e4m3 copies of the LLM's linear weights (one fp32 scale per output row) instead of the
         bf16 ones: half the HBM bytes per step.  Off by default: the reference computes in bf16 (include/callireader_hip.h)."""

@@ -14,8 +14,8 @@
   evaluate.py:389-436 main --type full_page               main (easy / medium / hard parquet files, prompt 读出图中所有文字。)
 
 The other CalliBench tasks (region_wise, choice, bilingual, intent) score different abilities with external judges and are
-outside SURVEY.md section 8.  `batch_pages` > 1 sends that many pages through the engine together
-(InternVLChatModel.chat_ocr_pages): each page's response equals its own chat_ocr call, pages/s is what changes.
+outside SURVEY.md section 8.  `batch_pages` > 1 sends that many pages through the engine together, two batches in flight
+(InternVLChatModel.chat_ocr_stream): each page's response equals its own chat_ocr call, pages/s is what changes.
 """
 import argparse
 import json
@@ -120,14 +120,17 @@ def test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model,
     to_be_save = {'detailed': []}
     sums = [0.0, 0.0, 0.0, 0.0]
     count = 0
-    for i0 in range(0, len(images), max(batch_pages, 1)):
-        imgs, annots = images[i0:i0 + batch_pages], annotations[i0:i0 + batch_pages]
-        if batch_pages > 1:
-            responses = [cc.convert(r) for r in model.chat_ocr_pages(tokenizer, detect_model, imgs, prompt, generation_config, use_p=use_p,
-                                                                     hard_vq=hard_vq, drop_zero=drop_zero, repetition_penalty=repetition_penalty)]
-        else:
-            responses = [single_rec(model, tokenizer, detect_model, generation_config, imgs[0], prompt, use_p, hard_vq, drop_zero,
-                                    repetition_penalty, verbose)]
+    step = max(batch_pages, 1)
+    groups = [(images[i0:i0 + step], annotations[i0:i0 + step]) for i0 in range(0, len(images), step)]
+    if batch_pages > 1:
+        # two batches in flight: batch i decodes while batch i+1 goes through detection, tiling, the visual stage and the prefill
+        answers = model.chat_ocr_stream(tokenizer, detect_model, (g[0] for g in groups), prompt, generation_config, use_p=use_p, hard_vq=hard_vq,
+                                        drop_zero=drop_zero, repetition_penalty=repetition_penalty)
+    else:
+        answers = ([single_rec(model, tokenizer, detect_model, generation_config, g[0][0], prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose)]
+                   for g in groups)
+    for (imgs, annots), responses in zip(groups, answers):
+        responses = [cc.convert(r) for r in responses] if batch_pages > 1 else responses
         for response, annot in zip(responses, annots):
             response, gt, precision, recall, f1, ned = score_page(response, annot['reference'])
             to_be_save['detailed'].append({'imgPath': annot['imagePath'], 'prompt': prompt, 'output': ''.join(response), 'gt': ''.join(gt),

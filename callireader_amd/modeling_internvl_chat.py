@@ -439,6 +439,38 @@ class InternVLChatModel:
         """Many pages at once (new: the reference's chat_ocr is one page per call, evaluate.py loops over it).  The
         character tiles of ALL pages go through the visual stage as one batch, the prompts are prefilled together and
         the pages decode as one batch; every page gets exactly the response its own chat_ocr call would produce."""
+        embeds, max_new, eos, template = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config, boxes_list, use_p, drop_zero,
+                                                          hard_vq, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN)
+        outs = self.generate_pages(embeds, max_new, eos, repetition_penalty)
+        return [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in outs]
+
+    def chat_ocr_stream(self, tokenizer, detect_model, image_batches, question, generation_config, boxes_batches=None, use_p=True,
+                        drop_zero=False, hard_vq=False, repetition_penalty=1.5, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>',
+                        IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]'):
+        """chat_ocr_pages over a sequence of page batches with two batches in flight (PagePipeline): a generator that yields one
+        list of responses per batch, in order; batch i decodes on a second stream while batch i+1 is detected, tiled, encoded and
+        prefilled.  Every page gets the response of its own chat_ocr call."""
+        pipe, template = None, None
+        try:
+            for b, images in enumerate(image_batches):
+                embeds, max_new, eos, template = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config,
+                                                                  boxes_batches[b] if boxes_batches is not None else None, use_p, drop_zero, hard_vq,
+                                                                  IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN)
+                if pipe is None:
+                    pipe = self.page_pipeline(max_new_tokens=max_new, eos_token_id=eos, repetition_penalty=repetition_penalty)
+                prev = pipe.start(embeds)
+                if prev is not None:
+                    yield [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in prev]
+            last = pipe.finish() if pipe is not None else None
+            if last is not None:
+                yield [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in last]
+        finally:
+            if pipe is not None:
+                pipe.close()
+
+    def _ocr_embeds(self, tokenizer, detect_model, images, question, generation_config, boxes_list, use_p, drop_zero, hard_vq,
+                    IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN):
+        """Everything of chat_ocr_pages before the language model: the pages' prompt embeddings with both splices done."""
         self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
         pages = [Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB') for im in images]
         page_px, n_tiles, char_px, n_chars = [], [], [], []
@@ -483,8 +515,7 @@ class InternVLChatModel:
                                                    ref_id=self.aligned_token_id))
             toff += n_tiles[i]
         max_new, eos = self._gen_args(generation_config)
-        outs = self.generate_pages(embeds, max_new, eos, repetition_penalty)
-        return [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in outs]
+        return embeds, max_new, eos, template
 
     def batch_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
                    return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
@@ -516,6 +547,10 @@ class InternVLChatModel:
         return [r.split(template.sep)[0].strip() for r in responses]
 
     # ---- page-parallel generation (new: the reference decodes one page at a time) ---------------
+    def page_pipeline(self, **kw):
+        """A PagePipeline over this model: batches of pages with the decode of one batch beside the visual stage of the next."""
+        return PagePipeline(self, **kw)
+
     def generate_pages(self, embeds_list, max_new_tokens=1024, eos_token_id=EOS_TOKEN_ID, repetition_penalty=1.0,
                        check_every=16, prefill_batch=16):
         """Prefill every page, then decode all unfinished pages as ONE batch per step: the 14.7 GB of LLM weights are
@@ -554,6 +589,130 @@ class InternVLChatModel:
                     ids = ids[:ids.index(eos_token_id) + 1]
             outs.append(ids)
         return outs
+
+
+class PagePipeline:
+    """Two batches of pages in flight.  The batched decode is HBM-bound (weights + KV cache streamed once per step) and leaves the
+    matrix cores idle; the visual stage and the prefill of the NEXT batch are matrix-bound.  A worker thread decodes batch i-1 on
+    its own HIP stream, through a second context that shares this model's weights (Engine.share_weights_from: own workspace, no
+    copy), while the caller runs batch i's visual stage and prefill as usual.  Measured on MI355X: a 63-tile ViT chunk takes 54 ms
+    instead of 50 beside a decode step that takes 26 ms instead of 11, i.e. 1.33x the work per unit time while both run.  The
+    two streams have to be fed by two host threads: one thread alternating between them got a quarter of that (scripts/overlap_probe.py).
+    Per page the ids are those of generate_pages (same kernels, same order per page).
+
+        pipe = model.page_pipeline(max_new_tokens=..., eos_token_id=...)
+        for batch in batches:
+            embeds = ... visual stage of `batch`, as for generate_pages ...
+            outs_prev = pipe.start(embeds)                 # prefill; returns the PREVIOUS batch's ids (None the first time)
+        outs_last = pipe.finish()
+        pipe.close()
+
+    The two KV caches alternate between batches."""
+
+    def __init__(self, model, max_new_tokens=1024, eos_token_id=EOS_TOKEN_ID, repetition_penalty=1.0, check_every=16, prefill_batch=16):
+        import queue
+        import threading
+        from .engine import Engine
+        self.m, self.eng = model, model.engine
+        self.max_new_tokens, self.eos, self.penalty = max_new_tokens, eos_token_id, repetition_penalty
+        self.check_every, self.prefill_batch = check_every, prefill_batch
+        self.dec = Engine(self.eng.dims, device=self.eng.device.index, max_pos=self.eng.max_pos)
+        self.dec.share_weights_from(self.eng)
+        # a stream of another priority level also lands on another hardware queue than the caller's (two streams of one level may share one)
+        self.side = torch.cuda.Stream(device=self.eng.device, priority=int(os.environ.get('CR_PIPE_PRIO', '-1')))
+        self.kvs = [None, None]
+        self.turn = 0
+        self.jobs, self.results = queue.Queue(), queue.Queue()
+        self.in_flight = 0
+        self.worker = threading.Thread(target=self._decode_loop, daemon=True)
+        self.worker.start()
+
+    def _kv(self, slot, P):
+        kv = self.kvs[slot]
+        if kv is None or kv.n_seqs < P:
+            if kv is not None:
+                kv.free()
+            kv = self.kvs[slot] = self.eng.kv_alloc(max(P, self.m.max_pages), self.m.max_tokens)
+        return kv
+
+    def _decode_loop(self):
+        torch.cuda.set_device(self.eng.device)
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            kv, P, ready = job
+            try:
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ready)                        # the prefill that filled this cache, on the caller's stream
+                    live, done, n = list(range(P)), {}, 1
+                    while n < self.max_new_tokens and live:
+                        steps = min(self.check_every, self.max_new_tokens - n)
+                        for _ in range(steps):
+                            self.dec.decode(kv, live, penalty=self.penalty)
+                        n += steps
+                        if self.eos is not None:
+                            for i in list(live):
+                                ids = kv.generated(i)                  # synchronises the side stream only
+                                if self.eos in ids:
+                                    done[i] = ids[:ids.index(self.eos) + 1]
+                                    live.remove(i)
+                    outs = []
+                    for i in range(P):
+                        ids = done.get(i)
+                        if ids is None:
+                            ids = kv.generated(i)[:self.max_new_tokens]
+                            if self.eos is not None and self.eos in ids:
+                                ids = ids[:ids.index(self.eos) + 1]
+                        outs.append(ids)
+                self.results.put(outs)
+            except BaseException as e:                                 # hand the failure to the caller's thread
+                self.results.put(e)
+
+    def _collect(self):
+        if not self.in_flight:
+            return None
+        self.in_flight -= 1
+        out = self.results.get()
+        if isinstance(out, BaseException):
+            raise out
+        return out
+
+    def start(self, embeds_list):
+        """Prefill a batch on the caller's stream and hand it to the decode thread; returns the previous batch's ids (None if there
+        was none), waiting for them if they are not there yet."""
+        P = len(embeds_list)
+        self._kv(self.turn ^ 1, P)                  # both caches exist from the first batch on (28 GB each at 64 pages: not in a later step)
+        kv = self._kv(self.turn, P)                # last used two batches ago, and that batch has been collected
+        self.turn ^= 1
+        kv.reset()
+        for i0 in range(0, P, self.prefill_batch):
+            idx = list(range(i0, min(P, i0 + self.prefill_batch)))
+            self.eng.prefill_batch(kv, idx, [embeds_list[i] for i in idx], penalty=self.penalty)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        prev = self._collect()
+        self.jobs.put((kv, P, ready))
+        self.in_flight += 1
+        return prev
+
+    def finish(self):
+        return self._collect()
+
+    def close(self):
+        if self.worker is not None:
+            while self.in_flight:
+                self._collect()
+            self.jobs.put(None)
+            self.worker.join()
+            self.worker = None
+        for kv in self.kvs:
+            if kv is not None:
+                kv.free()
+        self.kvs = [None, None]
+        if self.dec is not None:
+            self.dec.close()
+            self.dec = None
 
 
 def load_boxes_json(path):

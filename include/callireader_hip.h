@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 4   /* 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 5   /* 5: cr_share_weights; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -53,6 +53,15 @@ int cr_abi_version(void);
 /* InternVLChatModel.__init__ (InternVL/modeling_internvl_chat.py:136-194) */
 int cr_create(int device, const cr_model_desc* desc, cr_ctx** out);
 int cr_destroy(cr_ctx* ctx);
+/* Two stages in flight (the batched decode of one batch of pages beside the visual stage and prefill of the next; the reference runs
+ * page after page, modeling_internvl_chat.py:649-762 -- a throughput arrangement above the same per-page results).  A context is
+ * not re-entrant: its stage entry points carve their activations out of one grow-only workspace.  cr_share_weights makes `dst`
+ * (fresh from cr_create with the same description) use the weights, derived tensors and fp8 copies of the finalized `src` WITHOUT
+ * copying them: a second host thread can then run stages through `dst` on its own stream (own workspace, own profiler) while
+ * the first works through `src`.  KV caches (cr_kv_alloc) are plain device state and may be filled through one context and read
+ * through the other; ordering between the two streams is the caller's (events).  `src` must outlive `dst`; call again after
+ * reloading weights or toggling the fp8 options on `src`. */
+int cr_share_weights(cr_ctx* dst, const cr_ctx* src);
 /* One call per checkpoint tensor; `name` is the safetensors key (InternVL/model.safetensors.index.json), or
  *   "calli.mu" / "calli.sigma"  (vocab,1)  — params/gauss_norm_mu_sigma.pth columns (modeling_internvl_chat.py:153-155)
  *   "rope.cos" / "rope.sin"     (max_pos,128) bf16 — InternLM2DynamicNTKScalingRotaryEmbedding cache

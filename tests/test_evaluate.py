@@ -33,10 +33,11 @@ class FakeModel:
         self.calls.append((image.size, prompt, kw))
         return self.answers[len(self.calls) - 1], []
 
-    def chat_ocr_pages(self, tokenizer, detect_model, images, prompt, generation_config, **kw):
-        self.calls.append((tuple(im.size for im in images), prompt, kw))
-        n0 = sum(len(c[0]) if isinstance(c[0][0], tuple) else 1 for c in self.calls[:-1])
-        return self.answers[n0:n0 + len(images)]
+    def chat_ocr_stream(self, tokenizer, detect_model, image_batches, prompt, generation_config, **kw):
+        for images in image_batches:                       # the engine's generator yields one list of responses per batch, in order
+            self.calls.append((tuple(im.size for im in images), prompt, kw))
+            n0 = sum(len(c[0]) if isinstance(c[0][0], tuple) else 1 for c in self.calls[:-1])
+            yield self.answers[n0:n0 + len(images)]
 
 
 def make_parquet(path, refs):

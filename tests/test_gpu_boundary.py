@@ -168,6 +168,9 @@ def test_chat_ocr_pages_equals_per_page_calls(setup):
     singles = [m.chat_ocr(tok, det, im, '读出图中所有文字。', gen, repetition_penalty=1.0) for im in (img, img2)]
     both = m.chat_ocr_pages(tok, det, [img, img2], '读出图中所有文字。', gen, repetition_penalty=1.0)
     assert both == singles
+    # the same pages as a stream of batches, two batches in flight (decode of one beside the visual stage of the next)
+    streamed = list(m.chat_ocr_stream(tok, det, [[img], [img2, img], [img2]], '读出图中所有文字。', gen, repetition_penalty=1.0))
+    assert streamed == [[singles[0]], [singles[1], singles[0]], [singles[1]]]
 
 
 def test_dynamic_chat_and_generate(setup):

@@ -1,0 +1,72 @@
+"""PagePipeline (two batches of pages in flight: a worker thread decodes batch i-1 through a context that SHARES the weights,
+cr_share_weights, while the caller prefills batch i): per page the ids are those of generate_pages, batch after batch, with and
+without an EOS id, for batches of different sizes; and a context that borrows weights computes what their owner computes."""
+import pytest
+import torch
+
+from callireader_amd.config import ModelDims
+from callireader_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def model():
+    from callireader_amd.modeling_internvl_chat import InternVLChatModel
+    dims = ModelDims.reduced(vit_layers=1, llm_layers=2, rs_depth=1, vocab=8201)
+    sd = synthetic.make_state_dict(dims, parts=('llm',), seed=0)
+    m = InternVLChatModel.from_state_dict(sd, dims, max_tokens=768, max_pages=5)
+    yield m
+    m.engine.close()
+
+
+def batches(seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for sizes in ((40, 170, 33), (64,), (90, 20, 300, 51, 77), (128, 128)):
+        out.append([(torch.randn(S, 4096, generator=g) * 0.02).to(torch.bfloat16).cuda() for S in sizes])
+    return out
+
+
+@pytest.mark.parametrize('eos', [None, 'frequent'])
+def test_pipeline_ids_equal_generate_pages(model, eos):
+    bs = batches(3)
+    new_tokens = 24
+    ref = [model.generate_pages(b, max_new_tokens=new_tokens, eos_token_id=None) for b in bs]
+    eos_id = None
+    if eos == 'frequent':                                   # an id that some pages do emit: their rows leave the batch early
+        flat = [t for o in ref for ids in o for t in ids[3:]]
+        eos_id = max(set(flat), key=flat.count)
+        ref = [model.generate_pages(b, max_new_tokens=new_tokens, eos_token_id=eos_id, check_every=4) for b in bs]
+        assert any(len(ids) < new_tokens for o in ref for ids in o)
+    pipe = model.page_pipeline(max_new_tokens=new_tokens, eos_token_id=eos_id, check_every=4)
+    outs = []
+    for b in bs:
+        prev = pipe.start(b)
+        if prev is not None:
+            outs.append(prev)
+    outs.append(pipe.finish())
+    assert pipe.finish() is None                             # nothing left in flight
+    pipe.close()
+    assert outs == ref
+
+
+def test_borrowed_weights_compute_what_the_owner_computes(model):
+    from callireader_amd.engine import Engine
+    eng = model.engine
+    other = Engine(eng.dims, device=eng.device.index, max_pos=eng.max_pos)
+    other.share_weights_from(eng)
+    g = torch.Generator().manual_seed(9)
+    emb = (torch.randn(200, 4096, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    kv = eng.kv_alloc(2, 512)
+    a = eng.prefill(kv, 0, emb, want_logits=True)
+    b = other.prefill(kv, 1, emb, want_logits=True)         # same cache object, filled through the other context
+    s1 = eng.decode(kv, [1], want_logits=True)              # ... and read back through the owner
+    s0 = other.decode(kv, [0], want_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(s0, s1)
+    kv.free()
+    other.close()                                           # does not free the owner's weights
+    c = eng.prefill(eng.kv_alloc(1, 512), 0, emb, want_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)
