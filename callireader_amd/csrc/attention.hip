@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     // give every XCD a contiguous run of the (batch, head, x) space: the query blocks (or key splits) of one (batch, head)
     // read their K/V through ONE L2 instead of up to eight
     int bx, head, batch;
+    const int gx = gridDim.x;
     {
-        const int gx = gridDim.x, gy = gridDim.y;
+        const int gy = gridDim.y;
         const int total = gx * gy * (int)gridDim.z;
         const int lin = blockIdx.x + gx * (blockIdx.y + gy * (int)blockIdx.z);
         const int xcd = lin & 7, q = total >> 3, r = total & 7;
@@ -96,18 +97,28 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         head = (pid / gx) % gy;
         batch = pid / (gx * gy);
     }
-    const int qb = SPLIT ? 0 : bx;
+    // causal: the last query blocks have the most keys -- they go first, the short ones fill the tail of the launch
+    const int qb = SPLIT ? 0 : (CAUSAL ? gx - 1 - bx : bx);
     const int split = SPLIT ? bx : 0;
     const int kvh = head / p.kv_group;
-    const int slot = p.seq_map ? p.seq_map[batch] : batch;
-    const int Sk = p.sk_arr ? p.sk_arr[slot] + p.sk_add : p.Sk;
+    int slot = p.seq_map ? p.seq_map[batch] : batch;
+    int Sk = p.sk_arr ? p.sk_arr[slot] + p.sk_add : p.Sk;
+    int Sq = p.Sq, q_pos0 = p.q_pos0;
+    int64_t q_base = (int64_t)batch * p.q_bs, o_base = (int64_t)batch * p.o_bs;
+    if (CAUSAL && p.seg) {                                    // several pages' prompts in one launch (wave-uniform)
+        const int32_t* sg = p.seg + 4 * batch;
+        q_base = (int64_t)sg[0] * p.q_rs; o_base = (int64_t)sg[0] * p.o_rs;
+        Sq = sg[1]; q_pos0 = sg[2]; slot = sg[3];
+        Sk = q_pos0 + Sq;
+        if (qb * 128 >= Sq) return;                           // a shorter page has fewer query blocks
+    }
     const int qi = qb * 128 + wave * 32 + l31;
-    const int qi_c = min(qi, p.Sq - 1);
+    const int qi_c = min(qi, Sq - 1);
 
     // ---- Q fragment (B operand of K.Q^T): lane (query l31, half hh) holds Q[q][16ks + 8hh .. +7]
     bf16x8 qf[KS];
     {
-        const bf16* qp = p.Q + (int64_t)batch * p.q_bs + (int64_t)qi_c * p.q_rs + (int64_t)head * p.q_hs + hh * 8;
+        const bf16* qp = p.Q + q_base + (int64_t)qi_c * p.q_rs + (int64_t)head * p.q_hs + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             qf[ks] = *(const bf16x8*)(qp + ks * 16);
@@ -156,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 
     int nt = (Sk + 63) / 64;
     if (CAUSAL) {
-        const int kmax = p.q_pos0 + min(qb * 128 + 127, p.Sq - 1);
+        const int kmax = q_pos0 + min(qb * 128 + 127, Sq - 1);
         nt = min(nt, kmax / 64 + 1);
     }
-    const int qpos = p.q_pos0 + qi_c;
+    const int qpos = q_pos0 + qi_c;
     const float inv_div = 1.0f / p.s_div;     // reference divides by sqrt(d); x * (1/d) differs from x / d by <= 1 fp32 ulp before the bf16 rounding
     int t_begin = 0;
     if (SPLIT) {
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         const char* vbuf = kbuf + TILE;
         // a wave whose 32 query rows are all padding (ragged last query block; decode's 4-row blocks) only helps
         // staging (wave-uniform branch)
-        if (qb * 128 + wave * 32 < p.Sq) {
+        if (qb * 128 + wave * 32 < Sq) {
         // (a ragged last key tile runs both 32-key halves: the empty one is masked to -inf anyway, and skipping it
         //  cost every tile 16 accumulator-zeroing moves plus two branches on an issue-bound loop)
 
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         // A pair of scores is rounded to bf16 by ONE v_cvt_pk_bf16_f32 and stays packed until the exponentials; the
         // row maximum is taken on the raw accumulators (rounding is monotonic, so max(round(s)) = round(max(s))) with
         // v_max3_f32.  Masking only on tiles that need it.
-        const bool need_mask = (kt * 64 + 64 > Sk) || (CAUSAL && kt * 64 + 63 > p.q_pos0 + qb * 128 + wave * 32);
+        const bool need_mask = (kt * 64 + 64 > Sk) || (CAUSAL && kt * 64 + 63 > q_pos0 + qb * 128 + wave * 32);
         unsigned ppk[2][8];                                   // P as packed bf16 pairs: the PV B-operand, 4 dwords per fragment
         // Lean form for unmasked tiles after the first (no mask, no divisor: the ViT): the reference point of exp(s - m)
         // stays where the first tile put it (<= the true row maximum); P is rounded to bf16, which has fp32's exponent
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (SPLIT) {
         // partials: un-normalised O (fp32), running max and row sum; merged by attn_combine_kernel
-        if (qi < p.Sq) {
+        if (qi < Sq) {
             const int64_t row = (((int64_t)batch * p.H + head) * p.nsplit + split) * p.Sq + qi;
             if (hh == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = l_tot; }
             float* po = p.part_o + row * D + 4 * hh;
@@ -331,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         return;
     }
     const float inv = 1.0f / l_tot;
-    if (qi < p.Sq) {
-        bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qi * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
+    if (qi < Sq) {
+        bf16* op = p.O + o_base + (int64_t)qi * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
 #pragma unroll
         for (int db = 0; db < DB; db++)
 #pragma unroll
@@ -403,7 +414,7 @@ int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t strea
 }
 
 int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream) {
-    if (p.Sq <= 0 || (p.Sk <= 0 && !p.sk_arr) || p.H <= 0 || p.B <= 0 || p.kv_group <= 0) return CR_ERR_ARG;
+    if (p.Sq <= 0 || (p.Sk <= 0 && !p.sk_arr && !p.seg) || p.H <= 0 || p.B <= 0 || p.kv_group <= 0 || (p.seg && !causal)) return CR_ERR_ARG;
     if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7) || (p.o_rs & 3)) return CR_ERR_ARG;
     if (head_dim == 64) return causal ? launch_t<64, true>(p, stream) : launch_t<64, false>(p, stream);
     if (head_dim == 128) return causal ? launch_t<128, true>(p, stream) : launch_t<128, false>(p, stream);

@@ -22,6 +22,9 @@ struct AttnParams {
     int nsplit;
     float* part_ml;
     float* part_o;
+    // causal prefill of several pages in ONE launch: batch b is segment seg[4b..4b+3] = {first row, rows, position of the first
+    // row, cache slot}: Q / O rows start at `first row` (q_bs / o_bs unused), keys = position + rows, Sq = the longest segment
+    const int32_t* seg;
 };
 
 constexpr int ATTN_SPLIT_TILES = 4;      // 256 keys per split: depends only on the row's own key count

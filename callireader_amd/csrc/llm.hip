@@ -299,7 +299,7 @@ struct Segment { int seq, row0, S, pos0; };     // a page's rows inside a batche
 
 // The decoder stack over M rows (prefill: M = all prompt rows of the pages in `segs`; decode: M = n sequences, one row each).
 int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vector<Segment>& segs, const int32_t* d_row_seq,
-               const int32_t* d_row_pos, const int32_t* d_seqs, int nsplit, hipStream_t st) {
+               const int32_t* d_row_pos, const int32_t* d_seqs, int nsplit, hipStream_t st, const int32_t* d_seg = nullptr) {
     const int ff = (int)WT(c, "derived.w13.0")->shape[0] / 2;
     Arena ar(c->ws);
     float* part = decode ? ar.take<float>(attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD)) : nullptr;
@@ -346,12 +346,12 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         if (!decode) {
             ap.q_bs = 0; ap.q_rs = D; ap.q_hs = HD; ap.o_bs = 0; ap.o_rs = D; ap.o_hs = HD;
             ap.B = 1; ap.H = NH; ap.kv_group = NH / NKV;
-            for (const Segment& sg : segs) {            // causal attention is per page; the linear layers see all pages at once
-                ap.Q = q + (size_t)sg.row0 * D; ap.O = ao + (size_t)sg.row0 * D;
-                ap.Sq = sg.S; ap.Sk = sg.pos0 + sg.S; ap.q_pos0 = sg.pos0;
-                ap.K = kc + (int64_t)sg.seq * ap.k_bs; ap.V = vc + (int64_t)sg.seq * ap.v_bs;
-                if (launch_flash_attn(ap, HD, true, st) != CR_OK) return cr_fail(CR_ERR_HIP, "prefill attention launch failed");
-            }
+            // causal attention is per page, the linear layers see all pages at once; the pages' query blocks go out as ONE launch
+            // (segments: first row, rows, first position, cache slot), longest blocks first: a launch per page left its 800
+            // workgroups of 2..50 key tiles each a ragged tail on 512 slots
+            ap.B = (int)segs.size(); ap.seg = d_seg; ap.Sq = 0;
+            for (const Segment& sg : segs) ap.Sq = sg.S > ap.Sq ? sg.S : ap.Sq;
+            if (launch_flash_attn(ap, HD, true, st) != CR_OK) return cr_fail(CR_ERR_HIP, "prefill attention launch failed");
         } else {
             // rows = the 4 query heads of one KV group, all at the same position: no mask needed
             ap.q_bs = D; ap.q_rs = HD; ap.q_hs = 4 * HD; ap.o_bs = D; ap.o_rs = HD; ap.o_hs = 4 * HD;
@@ -630,22 +630,27 @@ int cr_llm_prefill_batch(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const
     hipStream_t st = (hipStream_t)stream;
     const int V = c->d.vocab;
     const size_t lw = layers_ws(c, M);
-    CR_TRY(ws_ensure(c, lw + (size_t)M * D * 2 + (size_t)n * D * 2 + (size_t)n * V * 4 + (size_t)M * 8 + 8192));
+    CR_TRY(ws_ensure(c, lw + (size_t)M * D * 2 + (size_t)n * D * 2 + (size_t)n * V * 4 + (size_t)M * 8 + (size_t)n * 16 + 8192));
     bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
     bf16* hl = x + (size_t)M * D;
     float* lg = (float*)(((uintptr_t)(hl + (size_t)n * D) + 255) & ~(uintptr_t)255);
     int32_t* d_row_seq = (int32_t*)(((uintptr_t)(lg + (size_t)n * V) + 255) & ~(uintptr_t)255);
     int32_t* d_row_pos = d_row_seq + M;
+    int32_t* d_seg = d_row_pos + M;                 // 4 per page: first row, rows, first position, cache slot (the attention launch's segments)
     {
-        std::vector<int32_t> h(2 * (size_t)M);
+        std::vector<int32_t> h(2 * (size_t)M + 4 * segs.size());
         for (const Segment& sg : segs)
             for (int r = 0; r < sg.S; r++) { h[sg.row0 + r] = sg.seq; h[(size_t)M + sg.row0 + r] = sg.pos0 + r; }
+        for (size_t i = 0; i < segs.size(); i++) {
+            int32_t* e = h.data() + 2 * (size_t)M + 4 * i;
+            e[0] = segs[i].row0; e[1] = segs[i].S; e[2] = segs[i].pos0; e[3] = segs[i].seq;
+        }
         CR_HIP(hipMemcpyAsync(d_row_seq, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: staged before return
     }
     CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));
     kv->seqs_on_device.assign(seqs, seqs + n);
     CR_HIP(hipMemcpyAsync(x, embeds, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));
-    CR_TRY(run_layers(c, kv, x, M, false, segs, d_row_seq, d_row_pos, nullptr, 0, st));
+    CR_TRY(run_layers(c, kv, x, M, false, segs, d_row_seq, d_row_pos, nullptr, 0, st, d_seg));
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!nw || !ow) return CR_ERR_STATE;
     // only each page's last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)
