@@ -61,7 +61,8 @@ SIGNATURES = {
     'cr_op_gemm': (i32, [i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     'cr_op_layernorm': (i32, [vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     'cr_op_rmsnorm': (i32, [vp, vp, vp, i64, i32, f32, vp]),
-    'cr_op_norm_fp8': (i32, [vp, vp, vp, i64, i32, f32, vp, vp, vp]),
+    'cr_op_norm_fp8': (i32, [vp, vp, vp, i64, i32, f32, vp, vp, vp, vp, vp]),
+    'cr_op_gemm_q8': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'cr_op_attention': (i32, [vp, vp, vp, vp, C.POINTER(i64), i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]),
 }
 

@@ -224,6 +224,16 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     return CR_OK;
 }
 
+int cr_op_gemm_q8(const void* a8, const float* ascale, const void* w8, const float* wscale, const void* bias, const float* c8scale,
+                  void* c8, int M, int N, int K, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)a8; p.lda = K; p.W = (const bf16*)w8; p.ldw = K; p.C = c8; p.ldc = N; p.bias = (const bf16*)bias; p.M = M; p.N = N; p.K = K;
+    p.w8 = 1; p.wscale = wscale; p.a8 = 1; p.ascale = ascale; p.c8scale = c8scale;
+    const int r = launch_gemm(EPI_GELU_Q8, p, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_gemm_q8(M=%d, N=%d, K=%d) rejected or failed to launch", M, N, K);
+    return CR_OK;
+}
+
 int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* beta, int64_t rows, int n, float eps,
                     int pixel_shuffle, void* stream) {
     NormParams p{};
@@ -235,9 +245,10 @@ int cr_op_layernorm(const void* in, void* out, const void* gamma, const void* be
 }
 
 int cr_op_norm_fp8(const void* in, const void* gamma, const void* beta, int64_t rows, int n, float eps, void* out8, float* out_scale,
-                   void* stream) {
-    if (!in || !gamma || !out8 || !out_scale) return cr_fail(CR_ERR_ARG, "cr_op_norm_fp8: null argument");
+                   float* next_scale, const float* next_bound, void* stream) {
+    if (!in || !gamma || !out8 || !out_scale || ((next_scale != nullptr) != (next_bound != nullptr))) return cr_fail(CR_ERR_ARG, "cr_op_norm_fp8: bad argument");
     NormParams p{};
+    p.next_scale = next_scale; p.next_bound = next_bound;
     p.in = (const bf16*)in; p.ld_in = n; p.out = nullptr; p.ld_out = n; p.gamma = (const bf16*)gamma; p.beta = (const bf16*)beta;
     p.rows = rows; p.eps = eps; p.out8 = (unsigned char*)out8; p.out8_scale = out_scale;
     const int r = beta ? launch_layernorm(p, n, 0, (hipStream_t)stream) : launch_rmsnorm(p, n, (hipStream_t)stream);

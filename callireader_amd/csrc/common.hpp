@@ -127,6 +127,7 @@ enum GemmEpi {
     EPI_PATCH = 5,    // patch-embed: bf16(bf16(acc + bias) + pos[1 + m % G]) -> row (m / G) * (G + 1) + 1 + m % G
     EPI_F32 = 6,      // float(bf16(acc + bias))                            (logits: bf16 GEMM then .float())
     EPI_PARTIAL = 7,  // decode only (M <= 64): fp32 partial sums [S][M][N] of S K-slices, no bias; the consumer kernel sums them
+    EPI_GELU_Q8 = 9,  // e4m3 instance only: e4m3(bf16(gelu(bf16(acc + bias))) / c8scale[m]) -- fc1's output as fc2's fp8 operand, no bf16 copy
     EPI_ARGMAX = 8,   // cosine VQ: C[m][b] = {col, bits(max)} of bf16(acc) over the 64 columns of block b (first max wins); nothing else stored
 };
 
@@ -147,6 +148,7 @@ struct GemmParams {
     // (K % 256 == 0), ascale[m] restores row m: C = epi((A8 . W8^T) * ascale[m] * wscale[n] + bias)
     int a8;
     const float* ascale;
+    const float* c8scale;      // EPI_GELU_Q8: C is e4m3 bytes [M][ldc], row m divided by c8scale[m] (an upper bound of the row's magnitude / 448)
 };
 
 // EPI_ARGMAX partial of one row and one 64-column block: the bf16-rounded maximum (as fp32 bits, high word) and its column

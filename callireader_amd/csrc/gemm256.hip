@@ -270,6 +270,50 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
     }
 }
 
+// EPI_GELU_Q8 (e4m3 instance only): fc1's output leaves as e4m3 bytes, row m divided by c8scale[m] -- a bound the LayerNorm in front
+// of fc1 derived from its row's norm (norm.hpp: next_scale), so no pass over the finished row is needed.  Per 16-row slice a lane
+// packs its 4 consecutive columns into one dword of a [16 rows][64 bytes] image (the dword's 16-byte group XORed with row >> 2:
+// the 64 lanes of a ds_write_b32 hit 64 banks), the slice is read back as 16-byte chunks and stored as 64-byte row segments.
+__device__ __forceinline__ void epilogue_gelu_q8(const GemmParams& p, const f32x4 (&acc)[8][4], char* stg, int row_base, int col0, int lane) {
+    const bool has_bias = p.bias != nullptr;
+    const int r = lane & 15, g = lane >> 4;
+    float bias_f[4][4], dq_f[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = min(col0 + j * 16 + g * 4, p.N - 4);
+        const f32x4 w = *(const f32x4*)(p.wscale + n);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { dq_f[j][e] = w[e]; bias_f[j][e] = has_bias ? bf2f(p.bias[n + e]) : 0.f; }
+    }
+    const int rr = lane >> 2, cc = lane & 3;
+#pragma unroll
+    for (int mf = 0; mf < 8; mf++) {
+        char* buf = stg + (mf & 1) * 1024;
+        const int m = min(row_base + mf * 16 + r, p.M - 1);
+        const float dq_row = p.ascale[m], inv_c = 1.0f / p.c8scale[m];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] = acc[mf][j][e] * (dq_row * dq_f[j][e]) + bias_f[j][e];
+            round_pair_bf16(x[0], x[1], x[0], x[1]);
+            round_pair_bf16(x[2], x[3], x[2], x[3]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] = rbf(gelu_erf(x[e])) * inv_c;
+            unsigned d = 0;
+            d = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], d, false);
+            d = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], d, true);
+            *(unsigned*)(buf + r * 64 + (((j ^ (r >> 2)) << 4) | (g << 2))) = d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 v = *(const u32x4*)(buf + rr * 64 + ((cc ^ (rr >> 2)) << 4));
+        const int gm = row_base + mf * 16 + rr, gn = col0 + cc * 16;
+        if (gm < p.M && gn + 16 <= p.N) __builtin_nontemporal_store(v, (u32x4*)((unsigned char*)p.C + (int64_t)gm * p.ldc + gn));
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 // F8 fragments live in the 8-register operand tuples of v_mfma_scale_f32_16x16x128_f8f6f4 from the start: the ds_read_b128 of
@@ -461,7 +505,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #endif       // the look-ahead (K-tile 0 and U0, U1 of K-tile 1 of the next tile) has landed: slots 1..4 rely on it
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----
-        epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
+        if (EPI == EPI_GELU_Q8) epilogue_gelu_q8(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
+        else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
 #ifdef CR_DIAG_STAMPS
         if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -506,6 +551,8 @@ int launch_gemm256_f8(int epi, const GemmParams& p8, hipStream_t stream) {
     switch (epi) {
         case EPI_STORE: return launch_t<EPI_STORE, true>(p, stream);
         case EPI_GELU: return launch_t<EPI_GELU, true>(p, stream);
+        case EPI_GELU_Q8: return (p.c8scale && (p.ldc & 15) == 0 && (((uintptr_t)p.C) & 15) == 0) ? launch_t<EPI_GELU_Q8, true>(p, stream) : CR_ERR_ARG;
+        case EPI_LS_RES: return (p.scale && p.res) ? launch_t<EPI_LS_RES, true>(p, stream) : CR_ERR_ARG;
         case EPI_RES: return p.res ? launch_t<EPI_RES, true>(p, stream) : CR_ERR_ARG;
         case EPI_SWIGLU: return launch_t<EPI_SWIGLU, true>(p, stream);
         case EPI_F32: return launch_t<EPI_F32, true>(p, stream);

@@ -253,6 +253,22 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restr
     }
 }
 
+// out[0] = max over rows of ||w_row||_2, out[1] = max |b| (positive floats order like their bit patterns: atomicMax on the bits)
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const bf16* __restrict__ w, int K, const bf16* __restrict__ b, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const bf16* wr = w + (int64_t)blockIdx.x * K;
+    float ss = 0.f;
+    for (int k = tid; k < K; k += 256) { const float v = bf2f(wr[k]); ss += v * v; }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        atomicMax((unsigned*)out, __float_as_uint(sqrtf(red[0] + red[1] + red[2] + red[3])));
+        if (b) atomicMax((unsigned*)out + 1, __float_as_uint(fabsf(bf2f(b[blockIdx.x]))));
+    }
+}
+
 int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
          int M, int N, int K, hipStream_t st) {
     GemmParams p{};
@@ -483,7 +499,20 @@ int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     // the linears whose input is a norm's output: that kernel emits the e4m3 row and its scale for free
     for (int l = 0; l < c->d.vit_layers; l++) {
         const std::string p = "vision_model.encoder.layers." + std::to_string(l) + ".";
-        if (c->w.count(p + "attn.qkv.weight")) { names.push_back(p + "attn.qkv.weight"); names.push_back(p + "mlp.fc1.weight"); }
+        if (!c->w.count(p + "attn.qkv.weight")) continue;
+        names.push_back(p + "attn.qkv.weight"); names.push_back(p + "mlp.fc1.weight"); names.push_back(p + "mlp.fc2.weight");
+        // fc1's output goes to fc2 as e4m3 straight from fc1's epilogue (EPI_GELU_Q8); its row scale is a bound LayerNorm 2 derives:
+        // "fp8b.<fc1>" = {max row norm of W1, max |b1|}
+        const DevTensor *w1 = WT(c, p + "mlp.fc1.weight"), *b1 = WT(c, p + "mlp.fc1.bias");
+        if (!w1 || !b1) return CR_ERR_STATE;
+        if (!c->w.count("fp8b." + p + "mlp.fc1.weight")) {
+            DevTensor t;
+            t.dtype = CR_F32; t.shape = {2}; t.bytes = 8;
+            if (hipMalloc(&t.ptr, 8) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "cr_enable_fp8_mfma: bound of layer %d", l);
+            CR_HIP(hipMemsetAsync(t.ptr, 0, 8, st));
+            hipLaunchKernelGGL(row_norm_max_kernel, dim3((unsigned)w1->shape[0]), dim3(256), 0, st, (const bf16*)w1->ptr, (int)w1->shape[1], (const bf16*)b1->ptr, (float*)t.ptr);
+            c->w["fp8b." + p + "mlp.fc1.weight"] = t;
+        }
     }
     if (c->w.count("mlp1.1.weight")) names.push_back("mlp1.1.weight");
     for (int l = 0; l < c->d.llm_layers; l++) {

@@ -48,14 +48,18 @@ __device__ __forceinline__ float row_max(float v, float* red, int tid) {
 // the normalised row as e4m3 + one scale (NormParams::out8): y is rounded to bf16 first, as the bf16 path stores it
 template <int TPR>
 __device__ __forceinline__ void store_row_e4m3(const NormParams& p, int64_t orow, int t, float* y, float* red, int tid, bool live) {
-    float mx = 0.f;
+    float mx = 0.f, ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; e++) { y[e] = rbf(y[e]); mx = fmaxf(mx, fabsf(y[e])); }
+    for (int e = 0; e < 16; e++) { y[e] = rbf(y[e]); mx = fmaxf(mx, fabsf(y[e])); ss += y[e] * y[e]; }
     mx = row_max<TPR>(mx, red, tid);
+    if (p.next_scale) ss = row_sum<TPR>(ss, red, tid);        // uniform branch
     const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
     if (!live) return;
     store16_e4m3(p.out8 + orow * (16 * TPR) + t * 16, y, 1.0f / sc);
-    if (t == 0) p.out8_scale[orow] = sc;
+    if (t == 0) {
+        p.out8_scale[orow] = sc;
+        if (p.next_scale) p.next_scale[orow] = fmaxf((1.13f * sqrtf(ss) * p.next_bound[0] + p.next_bound[1]) / 448.0f, 1e-30f);
+    }
 }
 
 template <int TPR, int MODE>   // MODE 0: plain rows, 1: pixel-shuffle gather (N = 4096 from [T,1025,1024])

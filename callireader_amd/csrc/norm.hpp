@@ -14,6 +14,11 @@ struct NormParams {
     // scale per row, out8_scale[row] = max|y| / 448 over the bf16-rounded normalised row y (1 for an all-zero row), q = RNE(y / scale);
     // `out` is then not written (the normalised row only feeds the next GEMM)
     unsigned char* out8; float* out8_scale;
+    // with out8: next_scale[row] = (1.13 * ||y||_2 * next_bound[0] + next_bound[1]) / 448, a bound on |y~ . w~_n + b_n| for every output n
+    // of the linear that follows (Cauchy-Schwarz; next_bound = {largest weight-row norm, largest |bias|} on the device, 1.13 = the
+    // slack of both operands' e4m3 rounding, 1.0625^2) -- the e4m3 scale that linear's epilogue may use for ITS output row without
+    // knowing the row's maximum (EPI_GELU_Q8)
+    float* next_scale; const float* next_bound;
 };
 
 // mode 0: rows of n (1024 | 4096) bf16; mode 1: pixel-shuffle gather feeding mlp1's LayerNorm (n = 4096)

@@ -58,6 +58,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
     bf16* qkv = ar.take<bf16>((size_t)M * C3);
     bf16* f = ar.take<bf16>((size_t)M * FF);
     float* hs = ar.take<float>((size_t)M);          // fp8 matrix-core path: one scale per LayerNorm row
+    float* fs = ar.take<float>((size_t)M);          // ... and per row of fc1's e4m3 output
 
     const bf16* patch_w = W(c, "derived.patch_w");
     const bf16* patch_b = W(c, "vision_model.embeddings.patch_embedding.bias");
@@ -85,7 +86,10 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         // cr_enable_fp8_mfma: the two LayerNorms emit e4m3 rows + scales (into h) and QKV / fc1 multiply e4m3 x e4m3
         const DevTensor *q_qkv = WTopt(c, "fp8." + p + "attn.qkv.weight"), *s_qkv = WTopt(c, "fp8s." + p + "attn.qkv.weight");
         const DevTensor *q_f1 = WTopt(c, "fp8." + p + "mlp.fc1.weight"), *s_f1 = WTopt(c, "fp8s." + p + "mlp.fc1.weight");
-        const bool m8 = c->fp8_mfma && q_qkv && s_qkv && q_f1 && s_f1;
+        const DevTensor *q_f2 = WTopt(c, "fp8." + p + "mlp.fc2.weight"), *s_f2 = WTopt(c, "fp8s." + p + "mlp.fc2.weight");
+        const DevTensor* bnd = WTopt(c, "fp8b." + p + "mlp.fc1.weight");
+        const bool m8 = c->fp8_mfma && q_qkv && s_qkv && q_f1 && s_f1 && q_f2 && s_f2 && bnd;
+
         NormParams np{};
         np.in = x; np.ld_in = C1; np.out = h; np.ld_out = C1; np.rows = M; np.eps = c->d.vit_ln_eps;
         np.gamma = n1w; np.beta = n1b;
@@ -104,17 +108,29 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         CR_TRY(gemm(c, EPI_LS_RES, h, C1, pw, C1, x, C1, pb, ls1, x, C1, M, C1, C1, 0, st));
 
         np.gamma = n2w; np.beta = n2b;
+        if (m8) { np.next_scale = fs; np.next_bound = (const float*)bnd->ptr; }
         CR_TRY(launch_layernorm(np, C1, 0, st));
-        if (m8) CR_TRY(ctx_gemm_f8(c, EPI_GELU, h, hs, q_f1, s_f1, f, FF, f1b, M, FF, C1, st));
-        else CR_TRY(gemm(c, EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
-        CR_TRY(gemm(c, EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
+        if (m8) {
+            // fc1 in e4m3, its GELU output written as e4m3 rows (scale = the bound LayerNorm 2 derived), fc2 in e4m3 on those rows
+            GemmParams g1{};
+            g1.A = h; g1.lda = C1; g1.W = (const bf16*)q_f1->ptr; g1.ldw = C1; g1.C = f; g1.ldc = FF; g1.bias = f1b; g1.M = M; g1.N = FF; g1.K = C1;
+            g1.w8 = 1; g1.wscale = (const float*)s_f1->ptr; g1.a8 = 1; g1.ascale = hs; g1.c8scale = fs;
+            CR_TRY(ctx_gemm(c, EPI_GELU_Q8, g1, st));
+            GemmParams g2{};
+            g2.A = f; g2.lda = FF; g2.W = (const bf16*)q_f2->ptr; g2.ldw = FF; g2.C = x; g2.ldc = C1; g2.bias = f2b; g2.scale = ls2; g2.res = x; g2.ldr = C1;
+            g2.M = M; g2.N = C1; g2.K = FF; g2.w8 = 1; g2.wscale = (const float*)s_f2->ptr; g2.a8 = 1; g2.ascale = fs;
+            CR_TRY(ctx_gemm(c, EPI_LS_RES, g2, st));
+        } else {
+            CR_TRY(gemm(c, EPI_GELU, h, C1, f1w, C1, f, FF, f1b, nullptr, nullptr, 0, M, FF, C1, 0, st));
+            CR_TRY(gemm(c, EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
+        }
     }
     return CR_OK;
 }
 
 static size_t vit_ws_bytes(int T) {
     const size_t M = (size_t)T * TOK;
-    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + M * 4 + 8192;
+    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + M * 8 + 8192;
 }
 
 static size_t project_ws_bytes(int T) { return (size_t)T * 256 * 4096 * 4 + (size_t)T * 256 * 4 + 8192; }   // a, b, row scales

@@ -309,13 +309,24 @@ def op_gemm_fp8x8(epi, a8, a_scale, q, sc, bias=None, out_dtype=torch.bfloat16):
     return Cc
 
 
-def op_norm_fp8(x, gamma, beta, eps):
-    """LayerNorm (beta given) or RMSNorm (beta None) of bf16 rows -> (uint8 e4m3 [rows, n], fp32 scale [rows])"""
+def op_norm_fp8(x, gamma, beta, eps, next_bound=None):
+    """LayerNorm (beta given) or RMSNorm (beta None) of bf16 rows -> (uint8 e4m3 [rows, n], fp32 scale [rows]); with next_bound
+    (device floats {largest weight-row norm, largest |bias|} of the next linear) also that linear's output-row scales [rows]"""
     rows, n = x.shape
     q = torch.empty(rows, n, device=x.device, dtype=torch.uint8)
     sc = torch.empty(rows, device=x.device, dtype=torch.float32)
-    B.check(B.lib.cr_op_norm_fp8(_p(x), _p(gamma), _p(beta), rows, n, float(eps), _p(q), _p(sc), _stream()), 'cr_op_norm_fp8')
-    return q, sc
+    nxt = torch.empty(rows, device=x.device, dtype=torch.float32) if next_bound is not None else None
+    B.check(B.lib.cr_op_norm_fp8(_p(x), _p(gamma), _p(beta), rows, n, float(eps), _p(q), _p(sc), _p(nxt), _p(next_bound), _stream()), 'cr_op_norm_fp8')
+    return (q, sc, nxt) if nxt is not None else (q, sc)
+
+
+def op_gemm_q8(a8, a_scale, q, sc, bias, c_scale):
+    """cr_op_gemm_q8: fc1 of the fp8 path -- e4m3 x e4m3, GELU, output as e4m3 rows divided by c_scale[m]"""
+    M, K = a8.shape
+    N = q.shape[0]
+    out = torch.zeros(M, N, device=a8.device, dtype=torch.uint8)
+    B.check(B.lib.cr_op_gemm_q8(_p(a8), _p(a_scale), _p(q), _p(sc), _p(bias), _p(c_scale), _p(out), M, N, K, _stream()), 'cr_op_gemm_q8')
+    return out
 
 
 def op_layernorm(x, gamma, beta, eps, pixel_shuffle=False):

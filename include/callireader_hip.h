@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 5   /* 5: cr_share_weights; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 5   /* 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -209,7 +209,13 @@ int cr_op_rmsnorm(const void* in, void* out, const void* gamma, int64_t rows, in
 /* the same norms with the fp8 output cr_enable_fp8_mfma uses: beta == NULL selects RMSNorm (n = 4096), otherwise LayerNorm
  * (n = 1024 | 4096); out8 = e4m3 [rows][n], out_scale = float[rows] */
 int cr_op_norm_fp8(const void* in, const void* gamma, const void* beta, int64_t rows, int n, float eps, void* out8, float* out_scale,
-                   void* stream);
+                   float* next_scale, const float* next_bound, void* stream);
+/* next_scale / next_bound (both or neither): next_scale[row] = (1.13 * ||y_row||_2 * next_bound[0] + next_bound[1]) / 448 -- an upper bound
+ * of what the next linear (largest weight-row norm next_bound[0], largest |bias| next_bound[1], device floats) can make of this row,
+ * used as the e4m3 scale of THAT linear's output row by cr_op_gemm_q8 / the ViT's fc1 under cr_enable_fp8_mfma. */
+/* C8 = e4m3(bf16(gelu(bf16((A8 . W8^T) * ascale[m] * wscale[n] + bias))) / c8scale[m]), bytes [M][N]: fc1's output as fc2's operand */
+int cr_op_gemm_q8(const void* a8, const float* ascale, const void* w8, const float* wscale, const void* bias, const float* c8scale,
+                  void* c8, int M, int N, int K, void* stream);
 /* q/k/v/o addressed as base + b*bs + row*rs + head*hs (elements) */
 int cr_op_attention(const void* q, const void* k, const void* v, void* o, const int64_t* strides12, int B, int H,
                     int Sq, int Sk, int head_dim, int kv_group, int causal, int q_pos0, float q_prescale, float s_div,

@@ -140,6 +140,39 @@ def test_norm_fp8_rows(E, kind, n):
     assert float((deq - y).abs().max() / y.abs().max()) <= 2 ** -4
 
 
+def test_fc1_writes_e4m3_rows_under_the_layernorm_bound(E):
+    """The ViT's MLP under cr_enable_fp8_mfma: LayerNorm 2 emits e4m3 rows, their scales AND a bound-based scale for fc1's output rows
+    (Cauchy-Schwarz on the row norm, the largest weight-row norm and the largest bias); fc1 (EPI_GELU_Q8) writes GELU(x W1^T + b) as
+    e4m3 under that scale with no pass over the finished row.  The bound must hold for every element (no saturation), the bytes
+    must be the e4m3 rounding of the bf16 GELU values, and the headroom the bound costs is reported."""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 4100, 4096, 1024
+    x = (torch.randn(M, K, generator=g) * 0.7 + 0.1).bfloat16().cuda()
+    gamma = (torch.randn(K, generator=g) * 0.2 + 1.0).bfloat16().cuda()
+    beta = (torch.randn(K, generator=g) * 0.1).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).bfloat16().cuda()
+    bound = torch.stack([W.float().norm(dim=1).max(), bias.float().abs().max()]).cuda()
+    a8, a_s, c_s = E.op_norm_fp8(x, gamma, beta, 1e-6, next_bound=bound)
+    w8, w_s = E.op_quantize_fp8(W)
+    out8 = E.op_gemm_q8(a8, a_s, w8, w_s, bias, c_s)
+    y = E.op_layernorm(x, gamma, beta, 1e-6).float()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(c_s, (1.13 * y.norm(dim=1) * bound[0] + bound[1]) / 448.0, rtol=1e-5, atol=0)
+    acc = (a8.view(torch.float8_e4m3fn).float() @ w8.view(torch.float8_e4m3fn).float().t()) * a_s[:, None] * w_s[None, :]
+    ref = rb(torch.nn.functional.gelu(rb(acc + bias.float())))
+    assert float((ref.abs().amax(dim=1) / (448.0 * c_s)).max()) < 1.0            # the bound holds: nothing saturates
+    deq = out8.view(torch.float8_e4m3fn).float() * c_s[:, None]
+    err = (deq - ref).abs()
+    # one e4m3 step (normal: 2^-3 of the value at the bottom of a binade; subnormal: 2^-9 of the scale): the fp32 sums differ in
+    # their last bits, so a value can land on the other side of a bf16 and then of an e4m3 rounding boundary -- never further
+    tol = ref.abs() * 2.0 ** -3 + c_s[:, None] * 2.0 ** -8 + 1e-6
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert float(err.double().norm() / ref.double().norm()) < 4e-2             # and on the whole it is e4m3's rounding noise (2^-4 / sqrt 3)
+    used = float((ref.abs().amax(dim=1) / (448.0 * c_s)).median())
+    print(f'fc1 -> e4m3 under the bound: the median row uses {used:.3f} of the scale ({-torch.log2(torch.tensor(used)).item():.1f} of e4m3\'s 15 binades given up)')
+
+
 def test_vit_and_projector_fp8_mfma_against_bf16():
     """Two ViT layers + mlp1 at full width.  Per e4m3 operand the relative rounding error is up to 2^-4 (rms 3.6 %), both operands
     of a product carry it, a K-long dot product of independent terms averages nothing away: each fp8 linear's output has ~5 % of
