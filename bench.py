@@ -351,7 +351,9 @@ def main():
                        'parallelism': f'character tiles sharded over ranks + RCCL all-gather of their pseudo-token embeddings, page tiles and LLM per page owner (round-robin), dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'tiled bf16 MFMA GEMM (gemm256_kernel, persistent 256x256, slot-staggered wave groups; gemm128_kernel where it schedules better), launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill',
                          'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                         'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
+                         'frac_one_batch_at_a_time': round(seq_frac, 4) if seq_frac else None,      # the same launches with the chip to themselves (see `pipeline`)
+                         'traffic': traffic,
                          'traffic_note': 'bytes per launch on the L2 fabric side (Infinity-Cache hits included), (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this bench: ' + str(traffic_src),
                          'algorithmic_bytes_per_launch': round(big_by / max(big_n, 1), 1),
                          'launches': int(big_n), 'avg_launch_ms': round(big_ms / max(big_n, 1), 4),
