@@ -245,7 +245,7 @@ def main():
             torch.cuda.synchronize()
 
     # everything below runs on a stream of its own, not on the legacy null stream (which synchronises with other streams' work)
-    main_stream = torch.cuda.Stream(device=dev)
+    main_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('CR_MAIN_PRIO', '0')))
     torch.cuda.set_stream(main_stream)
     if args.warmup:
         run_steps(args.warmup)
