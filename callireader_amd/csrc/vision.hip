@@ -12,12 +12,13 @@
 #include "misc.hpp"
 #include "norm.hpp"
 
-static constexpr int VIT_CHUNK = 63;   // 63*1025 rows = 253 row-tiles of 256: x4 column tiles = 3.95 rounds of 256 CUs
-// Chunks of 16k-1 tiles (63, 47, 31, 15) put ceil(rows/256) * {4,12,16} GEMM tiles just under a whole number of
+static constexpr int VIT_CHUNK = 255;  // 255*1025 rows = 1021 row-tiles of 256: x4 column tiles = 15.95 rounds of 256 CUs; per-launch fixed costs (cold
+                                       // start, tail) spread over 4x the work of round 1's 63-tile chunks: 1.3 % on 510 tiles; operands stay < 4 GiB
+// Chunks of 16k-1 tiles (127, ..., 31, 15) put ceil(rows/256) * {4,12,16} GEMM tiles just under a whole number of
 // 256-CU rounds; e.g. 32 tiles are run as 31 + 1 (129 row-tiles -> 125: the 129th held 32 rows and cost a round).
 static int next_chunk(int remaining) {
     static const int cap = [] { const char* e = getenv("CR_VIT_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 && v < VIT_CHUNK ? v : VIT_CHUNK; }();   // tuning aid
-    for (int c : {63, 47, 31, 15}) if (c <= cap && remaining >= c) return c;
+    for (int c : {255, 191, 127, 111, 95, 79, 63, 47, 31, 15}) if (c <= cap && remaining >= c) return c;
     return remaining < cap ? remaining : cap;
 }
 static constexpr int C1 = 1024, C3 = 3072, FF = 4096, TOK = 1025, KPAD = 640;
