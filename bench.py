@@ -299,6 +299,8 @@ def main():
     seq_ms, same_ids, seq_frac = None, None, None
     if pipe is not None:
         last_pipe = run_steps(1)[-1]
+        if os.environ.get('CR_PIPE_MARKS') and pipe.host_steps:
+            print(f'[marks] decode thread: {1e3 * pipe.host_s / pipe.host_steps:.2f} ms of host time per decode step issued ({pipe.host_steps} steps)', file=sys.stderr)
         pipe.close()                                # the decode thread, its context and both KV caches go before anything else is measured
         step()                                      # (the one-batch path allocates its own KV cache the first time)
         sync()

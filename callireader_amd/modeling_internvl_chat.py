@@ -14,6 +14,7 @@ whole front end of calli_align runs on its detections (ordering.py).  The detect
 """
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -624,6 +625,7 @@ class PagePipeline:
         self.turn = 0
         self.jobs, self.results = queue.Queue(), queue.Queue()
         self.in_flight = 0
+        self.host_s, self.host_steps = 0.0, 0         # host time the decode thread spent issuing steps (diagnostic)
         self.worker = threading.Thread(target=self._decode_loop, daemon=True)
         self.worker.start()
 
@@ -646,10 +648,17 @@ class PagePipeline:
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ready)                        # the prefill that filled this cache, on the caller's stream
                     live, done, n = list(range(P)), {}, 1
+                    span = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if os.environ.get('CR_PIPE_MARKS') else None
+                    if span:
+                        span[0].record(self.side)
+                        t_first = time.perf_counter()
                     while n < self.max_new_tokens and live:
                         steps = min(self.check_every, self.max_new_tokens - n)
+                        t0 = time.perf_counter()
                         for _ in range(steps):
                             self.dec.decode(kv, live, penalty=self.penalty)
+                        self.host_s += time.perf_counter() - t0
+                        self.host_steps += steps
                         n += steps
                         if self.eos is not None:
                             for i in list(live):
@@ -657,6 +666,12 @@ class PagePipeline:
                                 if self.eos in ids:
                                     done[i] = ids[:ids.index(self.eos) + 1]
                                     live.remove(i)
+                    if span:
+                        t_issued = time.perf_counter()
+                        span[1].record(self.side)
+                        span[1].synchronize()
+                        print(f'[marks] decode of a batch: {span[0].elapsed_time(span[1]):.0f} ms on the GPU, all steps issued after {1e3 * (t_issued - t_first):.0f} ms of host time',
+                              file=sys.stderr, flush=True)
                     outs = []
                     for i in range(P):
                         ids = done.get(i)
