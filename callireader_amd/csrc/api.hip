@@ -162,6 +162,7 @@ int cr_share_weights(cr_ctx* dst, const cr_ctx* src) {
 int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, const int64_t* shape, int ndim,
                    int src_is_host, void* stream) {
     if (!c || !name || !src || !shape || ndim <= 0 || ndim > 8) return cr_fail(CR_ERR_ARG, "cr_load_weight: bad argument");
+    if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_load_weight(%s): this context borrows its weights (cr_share_weights); load into the owner", name);
     const size_t es = dtype_size(dtype);
     if (!es) return cr_fail(CR_ERR_ARG, "cr_load_weight(%s): unknown dtype %d", name, dtype);
     DevTensor t;

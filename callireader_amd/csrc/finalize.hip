@@ -7,6 +7,7 @@ int llm_finalize(cr_ctx* c, hipStream_t st);
 
 extern "C" int cr_finalize(cr_ctx* c, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_finalize: null context");
+    if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_finalize: this context borrows its weights (cr_share_weights); finalize the owner");
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (c->w.count("vision_model.embeddings.patch_embedding.weight")) CR_TRY(vit_finalize(c, st));

@@ -433,7 +433,8 @@ int build_fp8_copy(cr_ctx* c, const std::string& nm, int k_multiple, hipStream_t
     DevTensor q, s;
     q.dtype = CR_U8; q.shape = src->shape; q.bytes = (size_t)N * K;
     s.dtype = CR_F32; s.shape = {N}; s.bytes = (size_t)N * 4;
-    if (hipMalloc(&q.ptr, q.bytes) != hipSuccess || hipMalloc(&s.ptr, s.bytes) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "fp8 copy: %s", nm.c_str());
+    if (hipMalloc(&q.ptr, q.bytes) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "fp8 copy: %s", nm.c_str());
+    if (hipMalloc(&s.ptr, s.bytes) != hipSuccess) { hipFree(q.ptr); return cr_fail(CR_ERR_NOMEM, "fp8 copy: %s", nm.c_str()); }
     hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, st, (const bf16*)src->ptr, K, (int)K, (unsigned char*)q.ptr, (float*)s.ptr);
     for (const char* pre : {"fp8.", "fp8s."}) {
         auto old = c->w.find(pre + nm);
@@ -492,6 +493,7 @@ int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float*
 int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_mfma: null context");
     if (!enable) { c->fp8_mfma = false; return CR_OK; }
+    if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -533,6 +535,7 @@ int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
 int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: null context");
     if (!enable) { c->fp8_decode = false; return CR_OK; }
+    if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;

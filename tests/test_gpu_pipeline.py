@@ -66,6 +66,11 @@ def test_borrowed_weights_compute_what_the_owner_computes(model):
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(s0, s1)
     kv.free()
+    from callireader_amd._binding import CalliReaderError
+    with pytest.raises(CalliReaderError):                   # a borrower cannot load, finalize or build fp8 copies
+        other.load_weight('language_model.model.norm.weight', torch.ones(4096, dtype=torch.bfloat16))
+    with pytest.raises(CalliReaderError):
+        other.enable_fp8_decode(True)
     other.close()                                           # does not free the owner's weights
     c = eng.prefill(eng.kv_alloc(1, 512), 0, emb, want_logits=True)
     torch.cuda.synchronize()
