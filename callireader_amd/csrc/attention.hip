@@ -69,7 +69,8 @@ template <int D> __device__ __forceinline__ int vswz(int r) { return D == 64 ? (
 // (scripts/ubench/valu_issue.hip: plain fp32 op 2.0-2.4 cycles per SIMD at 3 waves, v_cvt_pk / v_max3 3.0, v_exp 5.7).
 // Also measured and dropped: a 3-slot K/V ring (tile kt+2 requested during tile kt, counted vmcnt + raw s_barrier, DMA issued from
 // inline asm so that the compiler does not order the ds_reads behind it): 0.517 ms against 0.499-0.510 for this two-slot form in
-// the same run -- the fill's latency is not what the loop waits for.  The lean tile is 138 vector instructions + 16 MFMAs +
+// the same run -- the fill's latency is not what the loop waits for; workgroups of 2 waves (64 queries; twice the K/V fills per query,
+// 10 waves per CU: 0.62 ms) and of 8 waves (256 queries; one workgroup per CU: 0.56 ms) against 0.50-0.51 for these 4.  The lean tile is 138 vector instructions + 16 MFMAs +
 // 24 LDS reads per wave; per SIMD the three waves' vector (~1 340 cycles) and matrix (1 536) work would fit 2 880 cycles even
 // with no overlap at all, the measured round is ~5 400: the SIMD idles while all three waves sit at their workgroups' barriers.
 template <int D, bool CAUSAL, bool SPLIT = false, bool DIV = false>
