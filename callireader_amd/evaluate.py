@@ -13,6 +13,9 @@
   evaluate.py:134-171 test_full_page                      test_full_page (same arguments, same JSON layout) + `batch_pages`
   evaluate.py:389-436 main --type full_page               main (easy / medium / hard parquet files, prompt 读出图中所有文字。)
 
+  (new) --fp8_decode / --fp8_mfma                          BASELINE config 5's fp8 switches (off by default)
+  (new) one process per GPU under torchrun                 every rank takes a contiguous share of each file's pages, rows gathered on rank 0
+
 The other CalliBench tasks (region_wise, choice, bilingual, intent) score different abilities with external judges and are
 outside SURVEY.md section 8.  `batch_pages` > 1 sends that many pages through the engine together, two batches in flight
 (InternVLChatModel.chat_ocr_stream): each page's response equals its own chat_ocr call, pages/s is what changes.
@@ -113,10 +116,17 @@ def score_page(response, reference):
 
 
 def test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, prompt, use_p, hard_vq, drop_zero,
-                   repetition_penalty, verbose, batch_pages=1, limit=None):
+                   repetition_penalty, verbose, batch_pages=1, limit=None, shard=None, gather=None):
+    """shard = (rank, world): this process takes a contiguous share of the pages (one process per GPU, BASELINE config 5);
+    gather(list) -> list of all ranks' lists in rank order (e.g. torch.distributed.all_gather_object); the report holds every page
+    in file order and is written by rank 0."""
     images, annotations = get_parquet(parquet_path)
     if limit is not None:
         images, annotations = images[:limit], annotations[:limit]
+    rank, world = shard if shard is not None else (0, 1)
+    if world > 1:
+        lo, hi = len(images) * rank // world, len(images) * (rank + 1) // world
+        images, annotations = images[lo:hi], annotations[lo:hi]
     to_be_save = {'detailed': []}
     sums = [0.0, 0.0, 0.0, 0.0]
     count = 0
@@ -138,11 +148,17 @@ def test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model,
             for k, v in enumerate((precision, recall, f1, ned)):
                 sums[k] += v
             count += 1
+    if world > 1:
+        parts = gather(to_be_save['detailed'])
+        to_be_save['detailed'] = [row for part in parts for row in part]
+        count = len(to_be_save['detailed'])
+        sums = [sum(row[k] for row in to_be_save['detailed']) for k in ('precision', 'recall', 'f1', 'ned')]
     avg = [s / count for s in sums] if count else sums
     to_be_save['average'] = {'ave_precison': avg[0], 'avg_recall': avg[1], 'avg_f1': avg[2], 'avg_ned': avg[3]}     # keys as upstream (sic)
     to_be_save['t2s'] = cc.name
-    with open(save_json_path, 'w', encoding='utf-8') as f:
-        json.dump(to_be_save, f, ensure_ascii=False, indent=4)
+    if rank == 0:
+        with open(save_json_path, 'w', encoding='utf-8') as f:
+            json.dump(to_be_save, f, ensure_ascii=False, indent=4)
     return to_be_save['average']
 
 
@@ -159,6 +175,8 @@ def main(argv=None):
     parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
     parser.add_argument('--params', type=str, default='./params')
     parser.add_argument('--batch_pages', type=int, default=16, help='pages sent through the engine together')
+    parser.add_argument('--fp8_decode', action='store_true', help='BASELINE config 5: e4m3 weights for the batched decode (cr_enable_fp8_decode)')
+    parser.add_argument('--fp8_mfma', action='store_true', help='BASELINE config 5: e4m3 x e4m3 matrix-core linears in the ViT / projector / prefill (cr_enable_fp8_mfma)')
     args = parser.parse_args(argv)
     import torch
     from .inference import load_detector
@@ -166,7 +184,23 @@ def main(argv=None):
     from .tokenization_internlm2 import InternLM2Tokenizer
     save_dir = f'outputs/{args.save_name}'
     os.makedirs(save_dir, exist_ok=True)
-    model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16, max_pages=args.batch_pages).eval().cuda()
+    # one process per GPU (torchrun --nproc-per-node N -m callireader_amd.evaluate ...): every rank takes its share of each file's pages
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    gather = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(os.environ.get('CR_DIST_BACKEND', 'nccl'), device_id=torch.device('cuda', local))
+
+        def gather(rows):
+            out = [None] * world
+            dist.all_gather_object(out, rows)
+            return out
+    model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16, max_pages=args.batch_pages, device=local).eval().cuda()
+    if args.fp8_mfma:
+        model.engine.enable_fp8_mfma(True)
+    if args.fp8_decode:
+        model.engine.enable_fp8_decode(True)
     tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
     generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
     detect_model = load_detector(args.params)
@@ -175,8 +209,9 @@ def main(argv=None):
         parquet_path = os.path.join(args.data, f'full_page_ocr/{level}/{level}.parquet')
         save_json_path = os.path.join(save_dir, f'full_page_{level}.json')
         avg = test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, prompt, args.use_p, args.hard_vq,
-                             args.drop_zero, args.repetition_penalty, args.verbose, batch_pages=args.batch_pages)
-        print(level, avg)
+                             args.drop_zero, args.repetition_penalty, args.verbose, batch_pages=args.batch_pages, shard=(rank, world), gather=gather)
+        if rank == 0:
+            print(level, avg)
 
 
 if __name__ == '__main__':

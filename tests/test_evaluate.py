@@ -71,3 +71,30 @@ def test_full_page_report(tmp_path, batch_pages):
     assert abs(rep['average']['avg_ned'] - (0 + 2 / 7) / 2) < 1e-12 and avg == rep['average']
     assert len(model.calls) == (2 if batch_pages == 1 else 1)
     assert model.calls[0][1] == '读出图中所有文字。'
+
+
+def test_full_page_report_sharded_over_ranks(tmp_path):
+    """One process per GPU (BASELINE config 5): every rank scores its contiguous share of the pages, the rows are gathered in rank
+    order and rank 0 writes the same report a single process writes."""
+    pq = str(tmp_path / 'easy.parquet')
+    refs = ['君不见，黄河之水天上来！', '高堂明镜悲白发。', '朝如青丝暮成雪', '人生得意须尽欢']
+    answers = ['君不见黄河之水天上来', '高堂明镜白发发', '朝如青丝暮成雪', '人生得意']
+    make_parquet(pq, refs)
+    args = (None, None, dict(max_new_tokens=8), '读出图中所有文字。', True, False, False, 1.0, False)
+    single = str(tmp_path / 'single.json')
+    ev.test_full_page(pq, single, FakeModel(answers), *args, batch_pages=2)
+    # world 3 (shares of 1, 1, 2 pages): ranks 2 and 1 first, their rows handed to rank 0's gather
+    rows = {}
+    for rank in (2, 1):
+        lo, hi = 4 * rank // 3, 4 * (rank + 1) // 3
+        out = str(tmp_path / f'rank{rank}.json')
+        ev.test_full_page(pq, out, FakeModel(answers[lo:hi]), *args, batch_pages=2, shard=(rank, 3),
+                          gather=lambda r, rank=rank: [[], rows.setdefault(rank, r) if rank == 1 else [], rows.setdefault(rank, r) if rank == 2 else []])
+        assert not (tmp_path / f'rank{rank}.json').exists()             # only rank 0 writes
+    out0 = str(tmp_path / 'rank0.json')
+    avg = ev.test_full_page(pq, out0, FakeModel(answers[:1]), *args, batch_pages=2, shard=(0, 3), gather=lambda r: [r, rows[1], rows[2]])
+    a, b = json.load(open(single, encoding='utf-8')), json.load(open(out0, encoding='utf-8'))
+    assert a['detailed'] == b['detailed'] and [d['imgPath'] for d in b['detailed']] == ['p0.jpg', 'p1.jpg', 'p2.jpg', 'p3.jpg']
+    for k in a['average']:
+        assert abs(a['average'][k] - b['average'][k]) < 1e-12
+    assert avg == b['average']
