@@ -86,11 +86,17 @@ def main(argv=None):
     parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
     parser.add_argument('--params', type=str, default='./params')
     parser.add_argument('--boxes', type=str, default=None, help='labelme-style JSON with ordered character boxes')
+    parser.add_argument('--fp8_decode', action='store_true', help='e4m3 weights for the decode (cr_enable_fp8_decode; off by default: the reference computes in bf16)')
+    parser.add_argument('--fp8_mfma', action='store_true', help='e4m3 x e4m3 matrix-core linears in the ViT / projector / prefill (cr_enable_fp8_mfma; off by default)')
     args = parser.parse_args(argv)
     if not isinstance(args.tgt, str):
         raise ValueError(f'The target should a string, not a instance of {type(args.tgt)}!')
     from .tokenization_internlm2 import InternLM2Tokenizer
     model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16).eval().cuda()
+    if args.fp8_mfma:
+        model.engine.enable_fp8_mfma(True)
+    if args.fp8_decode:
+        model.engine.enable_fp8_decode(True)
     # the engine's own reader of tokenizer.model (+ tokenizer_config.json / added_tokens.json): the reference's
     # AutoTokenizer path needs sentencepiece==0.2.0; any HF-style tokenizer object works with chat_ocr as well
     tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
