@@ -116,6 +116,61 @@ def cpu_baseline():
                        f'{NEW_TOKENS} new tokens) = {page_s:.0f} s/page; sample wall {time.time() - t_all:.0f} s')}
 
 
+def cpu_baseline_full(threads):
+    """Calibration of the sample above: the oracle on ONE WHOLE page of the bench's shape -- 107 tiles through
+    24 ViT layers + mlp1, 96 of them through the 4-layer resampler + VQ + de-normalisation, splice, 3164-token prefill through 32
+    layers and DECODE_STEPS greedy steps -- timed stage by stage on this host; the decode is extrapolated to NEW_TOKENS from its
+    own measured steps only.  Never inside the timed region; `--cpu-baseline full`."""
+    from callireader_amd.config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID
+    from callireader_amd import synthetic
+    from oracle import vision, calli_align, generate, internlm2
+    DECODE_STEPS = 8
+    dims = ModelDims.full()
+    torch.set_num_threads(threads)
+    t = {}
+    with torch.no_grad():
+        sd = synthetic.make_state_dict(dims, parts=('vit', 'mlp1', 'resampler', 'vq'), seed=0)
+        page_px, char_px = synthetic.make_pixels(PAGE_TILES, seed=10), synthetic.make_pixels(CHAR_TILES, seed=20)
+        t0 = time.time()
+        feat_page = vision.extract_feature(sd, page_px, dims.vit_layers)
+        feat_char = torch.cat([vision.extract_feature(sd, char_px[i:i + 16], dims.vit_layers) for i in range(0, CHAR_TILES, 16)])
+        t['vit_mlp1_107_tiles_s'] = time.time() - t0
+        t0 = time.time()
+        rs = calli_align.resampler_forward(sd, feat_char, dims.rs_depth)
+        idx = calli_align.vq_cos_sim(sd['normed_emb.weight'], rs)
+        pseudo, _ = calli_align.denormalise(rs, idx, sd['normed_emb.weight'], sd['calli.mu'], sd['calli.sigma'])
+        t['resampler_vq_96_tiles_s'] = time.time() - t0
+        del sd
+        t0 = time.time()
+        lsd = synthetic.make_state_dict(dims, parts=('llm',), seed=0)
+        t['llm_weights_generated_s'] = time.time() - t0        # not part of a page
+        ids = build_ids(PAGE_TILES, CHAR_TILES, TEXT_TOKENS, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, 1000)[None]
+        emb = generate.splice_embeddings(lsd, ids, feat_page, pseudo, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID)
+        rope = internlm2.rope_tables(128)
+        t0 = time.time()
+        logits, past = internlm2.model_forward(lsd, dims.llm_layers, inputs_embeds=emb, rope=rope, all_logits=False)
+        t['prefill_3164_tokens_s'] = time.time() - t0
+        nxt = int(torch.argmax(logits[0, -1]))
+        t0 = time.time()
+        for _ in range(DECODE_STEPS):
+            logits, past = internlm2.model_forward(lsd, dims.llm_layers, input_ids=torch.tensor([[nxt]]), past=past, rope=rope)
+            nxt = int(torch.argmax(logits[0, -1]))
+        t['decode_s_per_token'] = (time.time() - t0) / DECODE_STEPS
+    page_s = t['vit_mlp1_107_tiles_s'] + t['resampler_vq_96_tiles_s'] + t['prefill_3164_tokens_s'] + t['decode_s_per_token'] * NEW_TOKENS
+    return {'what': f'the oracle on one whole page, stage by stage, {threads} threads of {os.cpu_count()} host cores; decode = {DECODE_STEPS} measured steps x {NEW_TOKENS}',
+            'cpu_model': _cpu_model(), 'stages': {k: round(v, 3) for k, v in t.items()}, 's_per_page': round(page_s, 1), 'pages_per_s': 1.0 / page_s}
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 NEW_TOKENS = 128
 
 
@@ -127,7 +182,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pages', type=int, default=64, help='pages per GPU per step (all pages of a step decode as one batch; 64 = the most rows the decode kernels take)')
     ap.add_argument('--new-tokens', type=int, default=128)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: --pages per GPU per step whatever N; strong: --total-pages per step over all GPUs (BASELINE config 4 as written: 64 pages over 8 GPUs = 8 per GPU)')
+    ap.add_argument('--total-pages', type=int, default=64, help='pages per step over all ranks with --scaling strong')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline', choices=('sample', 'full'), default='sample',
+                    help='sample: bounded sample extrapolated to one page (default, ~15 s); full: the oracle on ONE WHOLE example-shaped page (107 tiles, 24 + 4 + 32 layers, '
+                         '3164-token prefill, 8 decode steps; minutes of host time and ~25 GB of host memory), printed next to the extrapolation')
     ap.add_argument('--no-vit-extra', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='one batch at a time (the decode of a batch does not run beside the visual stage of the next)')
     args = ap.parse_args()
@@ -162,8 +223,10 @@ def main():
     from callireader_amd.parallel import shard_range, all_gather_rows_async, owned_pages
 
     dims = ModelDims.full()
-    P = args.pages
-    n_pages = P * world
+    n_pages = args.total_pages if args.scaling == 'strong' else args.pages * world
+    if n_pages < world:
+        raise SystemExit(f'--total-pages {n_pages} < {world} ranks: every rank needs a page')
+    P = len(owned_pages(n_pages, world, rank))           # pages this rank owns per step (round-robin; = --pages with weak scaling)
     S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
     model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=S_page + NEW_TOKENS + 64, max_pages=P)
     model.img_context_token_id = IMG_CONTEXT_TOKEN_ID
@@ -296,7 +359,7 @@ def main():
                   'note': 'inside a step the gather runs underneath the page tiles\' ViT (all_gather_rows_async)'}
 
     # one un-pipelined step for comparison (untimed extra) and a self-check: the pipelined run's ids are the sequential step's
-    seq_ms, same_ids, seq_frac = None, None, None
+    seq_ms, same_ids, seq_frac, seq_dec = None, None, None, None
     if pipe is not None:
         last_pipe = run_steps(1)[-1]
         if os.environ.get('CR_PIPE_MARKS') and pipe.host_steps:
@@ -313,6 +376,7 @@ def main():
         pr = (C.c_double * 8)()
         B.check(B.lib.cr_profile_read(eng._h, pr))
         seq_frac = (pr[2] / (pr[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if pr[1] > 0 else None      # the same kernels with the chip to themselves
+        seq_dec = (pr[7] / (pr[5] * 1e-3) / 1e9, pr[5]) if pr[5] > 0 else None                     # weight-streaming class, GB/s and ms of that un-overlapped step
         same_ids = bool(seq_out == last_pipe)
 
     # north_star's "MFMA utilisation on ViT + LLM prefill": one extra, untimed pass that stops after the first token
@@ -334,7 +398,7 @@ def main():
         value = n_pages / (elapsed / args.steps)
         big_n, big_ms, big_fl, big_by = prof[0], prof[1], prof[2], prof[3]
         traffic, traffic_src = None, None
-        for rd in ('round2', 'round1'):
+        for rd in ('round3', 'round2', 'round1'):
             tp = os.path.join(ROOT, 'profiles', rd, 'traffic_pmc.json')
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get('gemm_tiled_big', {}).get('traffic_bytes_per_launch')
@@ -345,11 +409,11 @@ def main():
         result = {
             'metric': 'calligraphy pages/sec (ViT+resampler+LLM greedy)', 'value': round(value, 4), 'unit': 'pages/s',
             'n_gpus': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'full page path, {P} pages/GPU/step of the examples/0.jpg shape (11 page + 96 char tiles 448x448, '
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': (f'{args.scaling} scaling: ' + (f'{n_pages} pages/step over {world} GPU(s) = ' if args.scaling == 'strong' else '')) + f'full page path, {P} pages/GPU/step of the examples/0.jpg shape (11 page + 96 char tiles 448x448, '
                                    f'{S_page}-token prompt, {NEW_TOKENS} greedy tokens, repetition_penalty 1.0); InternVL2-8B shapes '
                                    '(InternViT-300M 24L + mlp1 + PerceiverResampler 4L + 92553-row cosine VQ + InternLM2.5-7B 32L), random-init bf16 weights',
-                       'pages_per_gpu': P, 'tiles_per_page': PAGE_TILES + CHAR_TILES, 'prompt_tokens': S_page, 'new_tokens': NEW_TOKENS,
+                       'scaling': args.scaling, 'pages_per_step': n_pages, 'pages_per_gpu': P, 'tiles_per_page': PAGE_TILES + CHAR_TILES, 'prompt_tokens': S_page, 'new_tokens': NEW_TOKENS,
                        'parallelism': f'character tiles sharded over ranks + RCCL all-gather of their pseudo-token embeddings, page tiles and LLM per page owner (round-robin), dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'tiled bf16 MFMA GEMM (gemm256_kernel, persistent 256x256, slot-staggered wave groups; gemm128_kernel where it schedules better), launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill',
                          'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
@@ -365,7 +429,12 @@ def main():
             'decode_gemm': {'bound': 'hbm', 'kernel': 'gemm_skinny_kernel (weight streaming, M <= 64: batched decode, LM head) and tiled launches with M < 1024 (resampler rows)',
                             'achieved': round(sm_by / (sm_ms * 1e-3) / 1e9, 1) if sm_ms > 0 else 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                             'frac': round(sm_by / (sm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sm_ms > 0 else 0.0,
-                            'launches': int(sm_n), 'kernel_ms_per_step': round(sm_ms / args.steps, 2)},
+                            'launches': int(sm_n), 'kernel_ms_per_step': round(sm_ms / args.steps, 2),
+                            'achieved_one_batch_at_a_time': round(seq_dec[0], 1) if seq_dec else None,
+                            'frac_one_batch_at_a_time': round(seq_dec[0] / PEAK_HBM_GBS, 4) if seq_dec else None,
+                            'kernel_ms_one_batch_at_a_time': round(seq_dec[1], 2) if seq_dec else None,
+                            'note': 'achieved / frac are measured live in the timed steps, where these launches share the chip with the other batch\'s matrix-bound stages '
+                                    '(PagePipeline) and stretch; the *_one_batch_at_a_time fields are the same launches on one un-overlapped step -- that is the roofline reading'},
             'gemm_big_ms_per_step': round(big_ms / args.steps, 2),
             'prof_truncated': bool(pstat[2] != 0 or pstat[0] != pstat[1] or int(big_n + sm_n) != pstat[0]),
             'prof': {'launches_bracketed': int(pstat[0]), 'accounted': int(pstat[1]), 'lost': int(pstat[2]), 'peak_pending': int(pstat[3])},
@@ -528,6 +597,8 @@ def main():
         if not args.no_cpu_baseline:
             del model
             result['cpu_baseline'] = cpu_baseline()
+            if args.cpu_baseline == 'full':
+                result['cpu_baseline']['full_page'] = cpu_baseline_full(result['cpu_baseline']['cores'])
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False), flush=True)
     if world > 1:

@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ModelDesc(C.Structure):
@@ -29,6 +29,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     'cr_last_error': (C.c_char_p, []),
     'cr_abi_version': (i32, []),
+    'cr_build_id': (C.c_char_p, []),
     'cr_create': (i32, [i32, C.POINTER(ModelDesc), C.POINTER(vp)]),
     'cr_destroy': (i32, [vp]),
     'cr_load_weight': (i32, [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32, i32, vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     'cr_kv_generated': (i32, [vp, i32, C.POINTER(i64), i32, vp]),
     'cr_llm_prefill': (i32, [vp, vp, i32, vp, i32, f32, vp, vp]),
     'cr_llm_prefill_batch': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, C.POINTER(C.c_int32), f32, vp, vp]),
+    'cr_llm_hidden_probe': (i32, [vp, vp, i32, i32]),
     'cr_llm_decode': (i32, [vp, vp, C.POINTER(C.c_int32), i32, vp, f32, vp, vp]),
     'cr_share_weights': (i32, [vp, vp]),
     'cr_enable_fp8_decode': (i32, [vp, i32, vp]),

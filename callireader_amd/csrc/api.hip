@@ -111,10 +111,21 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
 
 static size_t dtype_size(int dt) { return dt == CR_BF16 ? 2 : dt == CR_F32 ? 4 : dt == CR_I64 ? 8 : dt == CR_I32 ? 4 : 0; }   // CR_U8 is internal: not loadable
 
+int ctx_share_ok(const cr_ctx* c, const char* who) {
+    if (c->borrowed && c->owner && c->owner->weight_gen != c->owner_gen)
+        return cr_fail(CR_ERR_STATE, "%s: the context that owns these weights reloaded, re-finalized or switched an fp8 option since cr_share_weights: share again", who);
+    return CR_OK;
+}
+
 extern "C" {
 
 const char* cr_last_error(void) { return g_err; }
 int cr_abi_version(void) { return CR_ABI_VERSION; }
+#ifndef CR_BUILD_ID
+#define CR_BUILD_ID "CR_BUILD_ID=unknown"
+#endif
+// the literal keeps its "CR_BUILD_ID=" tag so that build.py can find the id in the file without loading it
+const char* cr_build_id(void) { static const char id[] = CR_BUILD_ID; return id + 12; }
 
 int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     if (!desc || !out) return cr_fail(CR_ERR_ARG, "cr_create: null argument");
@@ -155,6 +166,7 @@ int cr_share_weights(cr_ctx* dst, const cr_ctx* src) {
     dst->d = src->d;
     dst->finalized = true;
     dst->fp8_decode = src->fp8_decode; dst->fp8_mfma = src->fp8_mfma;
+    dst->owner = src; dst->owner_gen = src->weight_gen;
     dst->weight_gen++;
     return CR_OK;
 }

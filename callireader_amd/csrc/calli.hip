@@ -262,6 +262,7 @@ int cr_resample(cr_ctx* c, const void* in, int T, void* out, void* stream) {
 int cr_vq(cr_ctx* c, const void* in, int n, int64_t* idx, void* cosv, void* stream) {
     if (!c || !in || !idx || n <= 0) return cr_fail(CR_ERR_ARG, "cr_vq: bad argument");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_vq: call cr_finalize first");
+    CR_TRY(ctx_share_ok(c, "cr_vq"));
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const DevTensor* tb = WT(c, "derived.vq_table");

@@ -28,12 +28,16 @@ struct cr_ctx {
     uint64_t weight_gen = 0;            // bumped by cr_load_weight / cr_finalize: captured graphs hold weight pointers
     bool fp8_decode = false;            // cr_enable_fp8_decode: batched decode streams e4m3 copies of the LLM's linear weights (half the bytes)
     bool fp8_mfma = false;              // cr_enable_fp8_mfma: the norm-fed linears of the ViT, the projector and the LLM prefill run e4m3 x e4m3 on the matrix cores
+    bf16* probe_dst = nullptr;          // cr_llm_hidden_probe: [layers + 1][probe_rows][4096] rows of the residual stream of the next prefills
+    int probe_row0 = 0, probe_rows = 0;
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
     std::unordered_map<std::string, DevTensor> w;
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
     bool borrowed = false;              // cr_share_weights: the tensors in `w` belong to another context (not freed here)
+    const cr_ctx* owner = nullptr;      // ... that context, and its weight_gen when the map was copied: a reload / re-finalize / fp8 toggle on the owner
+    uint64_t owner_gen = 0;             //     frees or replaces tensors this copy still points at -> the stage entry points refuse to run (ctx_share_ok)
     // small persistent device scratch (counters, argmax partials)
     char* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -51,6 +55,9 @@ int build_fp8_copy(cr_ctx* c, const std::string& name, int k_multiple, hipStream
 // C = epi((A8 . W8^T) * ascale[m] * wscale[n] + bias): both operands e4m3 (gemm256's F8 instance)
 int ctx_gemm_f8(cr_ctx* c, int epi, const void* a8, const float* ascale, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc,
                 const bf16* bias, int M, int N, int K, hipStream_t st, const bf16* res = nullptr, int64_t ldr = 0);
+
+// CR_OK, or CR_ERR_STATE when this context borrows weights whose owner has changed them since cr_share_weights
+int ctx_share_ok(const cr_ctx* c, const char* who);
 
 // GEMM launch used by every stage: validates, launches, and (when profiling) brackets the launch with events.
 int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st);

@@ -338,6 +338,14 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
               s_2 = decode ? gemm_partial_splits(D, ff) : 0;
     const bool sliced = decode && M <= 64 && s_qkv > 0 && s_o > 0 && s_2 > 0 && !c->no_sliced_decode;
     float* pbuf = sliced ? ar.take<float>((size_t)std::max(s_qkv * QKV, std::max(s_o, s_2) * D) * M) : nullptr;
+    // cr_llm_hidden_probe (parity tooling): rows [row0, row0 + rows) of the residual stream before layer 0 and after every layer
+    auto probe = [&](int slot) -> int {
+        if (!c->probe_dst || decode || c->probe_row0 + c->probe_rows > M) return CR_OK;
+        CR_HIP(hipMemcpyAsync(c->probe_dst + (size_t)slot * c->probe_rows * D, x + (size_t)c->probe_row0 * D, (size_t)c->probe_rows * D * 2,
+                              hipMemcpyDeviceToDevice, st));
+        return CR_OK;
+    };
+    CR_TRY(probe(0));
     for (int l = 0; l < c->d.llm_layers; l++) {
         LayerW w;
         CR_TRY(layer_weights(c, l, w));
@@ -410,6 +418,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             CR_TRY(f8 ? gemm8(c, EPI_RES, act, ff, w.q_2, w.s_2, x, D, x, D, M, D, ff, st)
                       : gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
         }
+        CR_TRY(probe(l + 1));
     }
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -492,7 +501,7 @@ int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float*
 
 int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_mfma: null context");
-    if (!enable) { c->fp8_mfma = false; return CR_OK; }
+    if (!enable) { if (c->fp8_mfma) c->weight_gen++; c->fp8_mfma = false; return CR_OK; }      // captured decode graphs are keyed on weight_gen
     if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
@@ -534,7 +543,7 @@ int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
 
 int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: null context");
-    if (!enable) { c->fp8_decode = false; return CR_OK; }
+    if (!enable) { if (c->fp8_decode) c->weight_gen++; c->fp8_decode = false; return CR_OK; }
     if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
@@ -647,6 +656,7 @@ int cr_llm_prefill_batch(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const
                          float* last_logits, void* stream) {
     if (!c || !kv || !seqs || !lens || !embeds || n <= 0 || n > kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_prefill_batch: bad argument");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_llm_prefill_batch: call cr_finalize first");
+    CR_TRY(ctx_share_ok(c, "cr_llm_prefill_batch"));
     std::vector<Segment> segs;
     int M = 0;
     for (int i = 0; i < n; i++) {
@@ -701,6 +711,12 @@ int cr_llm_prefill_batch(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const
     return CR_OK;
 }
 
+int cr_llm_hidden_probe(cr_ctx* c, void* dst, int row0, int rows) {
+    if (!c || (dst && (row0 < 0 || rows <= 0))) return cr_fail(CR_ERR_ARG, "cr_llm_hidden_probe: bad argument");
+    c->probe_dst = (bf16*)dst; c->probe_row0 = row0; c->probe_rows = dst ? rows : 0;
+    return CR_OK;
+}
+
 int cr_llm_prefill(cr_ctx* c, cr_kv* kv, int seq, const void* embeds, int S, float penalty, float* last_logits, void* stream) {
     if (!kv || S <= 0) return cr_fail(CR_ERR_ARG, "cr_llm_prefill: bad argument");
     const int32_t s = seq, l = S;
@@ -711,6 +727,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
                   void* stream) {
     if (!c || !kv || !seqs || n <= 0 || n > kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_decode: bad argument");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_llm_decode: call cr_finalize first");
+    CR_TRY(ctx_share_ok(c, "cr_llm_decode"));
     for (int i = 0; i < n; i++) {
         const int s = seqs[i];
         if (s < 0 || s >= kv->n_seqs) return cr_fail(CR_ERR_ARG, "cr_llm_decode: sequence %d out of range", s);

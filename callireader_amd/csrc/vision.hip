@@ -163,6 +163,7 @@ extern "C" {
 int cr_vit_forward(cr_ctx* c, const void* pixels, int T, void* out, void* stream) {
     if (!c || !pixels || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_vit_forward: bad argument");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_vit_forward: call cr_finalize after loading weights");
+    CR_TRY(ctx_share_ok(c, "cr_vit_forward"));
     CR_HIP(hipSetDevice(c->device));
     CR_TRY(ws_ensure(c, vit_ws_bytes(T < VIT_CHUNK ? T : VIT_CHUNK)));
     for (int t0 = 0; t0 < T;) {
@@ -190,6 +191,7 @@ int cr_project(cr_ctx* c, const void* vit_out, int T, void* out, void* stream) {
 int cr_extract_feature(cr_ctx* c, const void* pixels, int T, void* out, void* stream) {
     if (!c || !pixels || !out || T <= 0) return cr_fail(CR_ERR_ARG, "cr_extract_feature: bad argument");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_extract_feature: call cr_finalize after loading weights");
+    CR_TRY(ctx_share_ok(c, "cr_extract_feature"));
     CR_HIP(hipSetDevice(c->device));
     // ViT output of a chunk sits at the top of the workspace, below it the per-chunk scratch of both stages.
     for (int t0 = 0; t0 < T;) {

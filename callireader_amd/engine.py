@@ -213,6 +213,17 @@ class Engine:
                                            float(penalty), _p(logits), _stream()), 'cr_llm_prefill_batch')
         return logits
 
+    def hidden_probe(self, rows=None, row0=0):
+        """cr_llm_hidden_probe: `rows` > 0 arms it and returns the [llm_layers + 1, rows, 4096] bf16 tensor the next prefill fills
+        (residual stream before layer 0 and after each layer); rows=None disarms."""
+        if not rows:
+            B.check(B.lib.cr_llm_hidden_probe(self._h, C.c_void_p(0), 0, 0), 'cr_llm_hidden_probe')
+            self._probe = None
+            return None
+        self._probe = torch.zeros(self.dims.llm_layers + 1, rows, self.dims.llm_hidden, device=self.device, dtype=torch.bfloat16)
+        B.check(B.lib.cr_llm_hidden_probe(self._h, _p(self._probe), row0, rows), 'cr_llm_hidden_probe')
+        return self._probe
+
     def decode(self, kv, seqs, penalty=1.0, force_tokens=None, want_logits=False):
         n = len(seqs)
         seq_arr = (C.c_int32 * n)(*seqs)

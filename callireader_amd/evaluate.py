@@ -14,6 +14,8 @@
   evaluate.py:389-436 main --type full_page               main (easy / medium / hard parquet files, prompt 读出图中所有文字。)
 
   (new) --fp8_decode / --fp8_mfma                          BASELINE config 5's fp8 switches (off by default)
+  (new) --compare_fp8                                      the accuracy gate of those switches as ONE command: every file runs twice, bf16 then fp8,
+                                                          and full_page_<level>_fp8_vs_bf16.json holds the per-page agreement and the F1 / NED deltas
   (new) one process per GPU under torchrun                 every rank takes a contiguous share of each file's pages, rows gathered on rank 0
 
 The other CalliBench tasks (region_wise, choice, bilingual, intent) score different abilities with external judges and are
@@ -24,6 +26,7 @@ import argparse
 import json
 import os
 import re
+import sys
 from collections import Counter
 from io import BytesIO
 
@@ -91,6 +94,8 @@ class _T2S:
             self._cc, self.name = opencc.OpenCC('t2s.json'), 'opencc t2s'
         except Exception:
             self._cc, self.name = None, 'identity (opencc not installed)'
+            print('[callireader_amd.evaluate] WARNING: opencc is not installed -- responses are NOT converted traditional -> simplified, so P / R / '
+                  'F1 / NED are not comparable with the reference\'s evaluate.py numbers', file=sys.stderr)
 
     def convert(self, text):
         return self._cc.convert(text) if self._cc is not None else text
@@ -162,6 +167,27 @@ def test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model,
     return to_be_save['average']
 
 
+def compare_reports(bf16_rows, fp8_rows):
+    """--compare_fp8: the same pages through the bf16 path and through the fp8 switches -> what changed.  Rows are the `detailed`
+    entries test_full_page writes (same order).  The gate BASELINE config 5 needs is delta_f1 / delta_ned on real weights."""
+    assert len(bf16_rows) == len(fp8_rows)
+    n = len(bf16_rows)
+    same, ned_between = 0, 0.0
+    for a, b in zip(bf16_rows, fp8_rows):
+        assert a['imgPath'] == b['imgPath']
+        same += a['output'] == b['output']
+        m = max(len(a['output']), len(b['output']))
+        ned_between += edit_distance(list(a['output']), list(b['output'])) / m if m else 0.0
+
+    def avg(rows, k):
+        return sum(r[k] for r in rows) / n if n else 0.0
+    out = {'pages': n, 'identical_outputs': same, 'mean_ned_between_outputs': ned_between / n if n else 0.0}
+    for k in ('precision', 'recall', 'f1', 'ned'):
+        out[f'avg_{k}_bf16'], out[f'avg_{k}_fp8'] = avg(bf16_rows, k), avg(fp8_rows, k)
+        out[f'delta_{k}'] = out[f'avg_{k}_fp8'] - out[f'avg_{k}_bf16']
+    return out
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser(description='args for inference task')
     parser.add_argument('--type', type=str, choices=['full_page'], default='full_page', help='Evaluation Type (this engine covers full_page)')
@@ -177,7 +203,13 @@ def main(argv=None):
     parser.add_argument('--batch_pages', type=int, default=16, help='pages sent through the engine together')
     parser.add_argument('--fp8_decode', action='store_true', help='BASELINE config 5: e4m3 weights for the batched decode (cr_enable_fp8_decode)')
     parser.add_argument('--fp8_mfma', action='store_true', help='BASELINE config 5: e4m3 x e4m3 matrix-core linears in the ViT / projector / prefill (cr_enable_fp8_mfma)')
+    parser.add_argument('--compare_fp8', action='store_true', help='run every file twice -- bf16, then with --fp8_decode / --fp8_mfma (both when neither is given) -- and '
+                                                                   'write full_page_<level>_fp8_vs_bf16.json: identical outputs, NED between them, F1 / NED deltas')
+    parser.add_argument('--allow_no_t2s', action='store_true', help='run without opencc (responses stay unconverted: scores not comparable with the reference\'s)')
     args = parser.parse_args(argv)
+    if cc._cc is None and not args.allow_no_t2s:
+        raise SystemExit('opencc is not installed: the reference converts every response traditional -> simplified before scoring (evaluate.py:127-132). '
+                         'Install opencc, or pass --allow_no_t2s to score unconverted text (not comparable with the reference\'s numbers).')
     import torch
     from .inference import load_detector
     from .modeling_internvl_chat import InternVLChatModel
@@ -197,10 +229,17 @@ def main(argv=None):
             dist.all_gather_object(out, rows)
             return out
     model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16, max_pages=args.batch_pages, device=local).eval().cuda()
-    if args.fp8_mfma:
-        model.engine.enable_fp8_mfma(True)
-    if args.fp8_decode:
-        model.engine.enable_fp8_decode(True)
+    want_mfma, want_dec = args.fp8_mfma, args.fp8_decode
+    if args.compare_fp8 and not (want_mfma or want_dec):
+        want_mfma = want_dec = True
+
+    def fp8(on):
+        if want_mfma:
+            model.engine.enable_fp8_mfma(on)
+        if want_dec:
+            model.engine.enable_fp8_decode(on)
+    if not args.compare_fp8:
+        fp8(True)
     tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
     generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
     detect_model = load_detector(args.params)
@@ -208,10 +247,28 @@ def main(argv=None):
     for level in ('easy', 'medium', 'hard'):
         parquet_path = os.path.join(args.data, f'full_page_ocr/{level}/{level}.parquet')
         save_json_path = os.path.join(save_dir, f'full_page_{level}.json')
-        avg = test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, prompt, args.use_p, args.hard_vq,
-                             args.drop_zero, args.repetition_penalty, args.verbose, batch_pages=args.batch_pages, shard=(rank, world), gather=gather)
+        run = lambda path: test_full_page(parquet_path, path, model, tokenizer, detect_model, generation_config, prompt, args.use_p, args.hard_vq,   # noqa: E731
+                                          args.drop_zero, args.repetition_penalty, args.verbose, batch_pages=args.batch_pages, shard=(rank, world), gather=gather)
+        avg = run(save_json_path)
         if rank == 0:
             print(level, avg)
+        if args.compare_fp8:
+            fp8_path = os.path.join(save_dir, f'full_page_{level}_fp8.json')
+            fp8(True)
+            try:
+                avg8 = run(fp8_path)
+            finally:
+                fp8(False)
+            if rank == 0:
+                cmp = compare_reports(json.load(open(save_json_path, encoding='utf-8'))['detailed'], json.load(open(fp8_path, encoding='utf-8'))['detailed'])
+                cmp['switches'] = {'fp8_mfma': want_mfma, 'fp8_decode': want_dec}
+                with open(os.path.join(save_dir, f'full_page_{level}_fp8_vs_bf16.json'), 'w', encoding='utf-8') as f:
+                    json.dump(cmp, f, ensure_ascii=False, indent=4)
+                print(level, 'fp8', avg8, 'identical outputs', cmp['identical_outputs'], 'of', cmp['pages'], 'delta F1', cmp['delta_f1'], 'delta NED', cmp['delta_ned'])
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -156,16 +156,8 @@ class InternVLChatModel:
             return None, None                                               # :554-555
         img = Image.open(img_path).convert('RGB') if isinstance(img_path, str) else img_path.convert('RGB')
         if boxes is None:
-            if not callable(detect_model):
-                raise NotImplementedError('calli_align needs a detector: pass the ultralytics YOLO object the reference '
-                                          'uses (inference.py:98), any callable image -> boxes, or boxes=[(x1,y1,x2,y2),...]')
             from . import ordering
-            if self.sorter is not None:
-                raw = ordering.detect_all(detect_model, np.array(img))
-                boxes = ordering.sort_boxes(raw, img.width, img.height, self.sorter)      # :558
-            else:
-                # no params/orderformer.pth was loaded: the detector's own order is taken as the reading order
-                boxes = ordering.run_detector(detect_model, np.array(img))
+            boxes = ordering.acquire_boxes(detect_model, img, self.sorter)      # :346-394, :558 (one helper for chat_ocr and the page batches)
         arr = np.array(img)
         if self.gpu_preprocess:
             # one page upload, every crop resized/padded/normalised by cr_preprocess (replaces the per-box PIL loop :580-583)
@@ -484,8 +476,7 @@ class InternVLChatModel:
                 bx = boxes_list[i] if boxes_list is not None else None
                 if bx is None:
                     from . import ordering
-                    raw = ordering.detect_all(detect_model, np.array(page))
-                    bx = ordering.sort_boxes(raw, page.width, page.height, self.sorter) if self.sorter is not None else raw
+                    bx = ordering.acquire_boxes(detect_model, page, self.sorter)      # exactly what this page's own chat_ocr call does
                 w, h = page.size
                 jobs = [plan_char((max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), w), min(int(b[3]), h)), j) for j, b in enumerate(bx)]
                 char_px.append(self.engine.preprocess(arr, jobs, len(jobs)))
@@ -697,7 +688,11 @@ class PagePipeline:
         """Prefill a batch on the caller's stream and hand it to the decode thread; returns the previous batch's ids (None if there
         was none), waiting for them if they are not there yet."""
         P = len(embeds_list)
-        self._kv(self.turn ^ 1, P)                  # both caches exist from the first batch on (28 GB each at 64 pages: not in a later step)
+        # The OTHER slot may be under the worker's decode right now (the previous batch, not collected yet): it is only ever
+        # CREATED here, on the first batch (28 GB at 64 pages: not inside a later step), never regrown -- a batch larger than it
+        # holds regrows it when that slot's turn comes, i.e. after _collect() has returned the batch that last used it.
+        if self.kvs[self.turn ^ 1] is None:
+            self._kv(self.turn ^ 1, P)
         kv = self._kv(self.turn, P)                # last used two batches ago, and that batch has been collected
         self.turn ^= 1
         kv.reset()

@@ -55,16 +55,39 @@ def most_frequent_rgb(image):
     return ((top >> 16) & 255, (top >> 8) & 255, top & 255)
 
 
+def _takes_verbose(detector):
+    if hasattr(detector, 'predict'):
+        return True
+    import inspect
+    try:
+        params = inspect.signature(detector).parameters
+    except (TypeError, ValueError):
+        return False
+    return 'verbose' in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
+def acquire_boxes(detector, image, sorter):
+    """The box acquisition of calli_align (modeling_internvl_chat.py:346-394,558), shared by chat_ocr and the batched page
+    path: with a sorter, repeated detection passes + the reference's ordering front end; without one, a single detector pass
+    whose order is taken as the reading order."""
+    if not callable(detector):
+        raise NotImplementedError('calli_align needs a detector: pass the ultralytics YOLO object the reference '
+                                  'uses (inference.py:98), any callable image -> boxes, or boxes=[(x1,y1,x2,y2),...]')
+    arr = np.array(image)
+    if sorter is not None:
+        return sort_boxes(detect_all(detector, arr), image.width, image.height, sorter)
+    return run_detector(detector, arr)
+
+
 def run_detector(detector, image):
     """One detection pass -> [[x1, y1, x2, y2], ...] (ints, truncated as the reference does).
 
     `detector` is what the reference hands to chat_ocr (inference.py:37-42,98): an ultralytics `YOLO` object, used as
     `detector(image_array, verbose=False)[0].boxes[i].xyxy` (modeling_internvl_chat.py:356-362) -- or any callable
     `image_array -> iterable of (x1, y1, x2, y2, ...)` (tests, other detectors)."""
-    try:
-        res = detector(image, verbose=False)
-    except TypeError:
-        res = detector(image)
+    # the ultralytics call shape is chosen by looking at the object (a YOLO model has .predict), not by catching TypeError:
+    # a TypeError raised INSIDE a real detector must surface, not trigger a silent second run
+    res = detector(image, verbose=False) if _takes_verbose(detector) else detector(image)
     first = res[0] if isinstance(res, (list, tuple)) and len(res) and hasattr(res[0], 'boxes') else None
     if first is None and hasattr(res, 'boxes'):
         first = res

@@ -198,3 +198,85 @@ def orderformer_keys(cfg=ORDERFORMER):
 def make_orderformer_state_dict(seed=0, device='cpu', dtype=torch.bfloat16, cfg=ORDERFORMER):
     return {k: _randn('orderformer.' + k, shape, std, seed, device, dtype, mean=mean)
             for k, (shape, std, mean) in orderformer_keys(cfg).items()}
+
+
+# ---- margin-controlled ("peaked") language model ---------------------------------------------------------------
+# Random-init weights make the logits nearly flat (typical top-2 margin 0.1-0.9 at |logit| <= 5.5): the unfavourable
+# case for a token-exactness test, because any second bf16 implementation flips such near-ties.  This checkpoint keeps the
+# architecture, every key and every tensor of the seed-0 set EXCEPT three families, so that the reference's own greedy loop
+# (InternVL/modeling_internvl_chat.py:1111-1120 -> modeling_internlm2.py:1022-1149) decodes with a top-2 margin of ~2-4 at |logit| ~ 12:
+#   * wo / w2 of every layer: the seed-0 tensors times 2^-PEAKED['branch_shift'] (exact in bf16) -- the 64 residual
+#     branches together add about as much to the residual stream as the token embedding it started from, instead of
+#     swamping it 100:1;
+#   * output.weight = N(0, noise_std) + a * E[T1^-1] + runner * a * E[T2^-1] + a few override rows, E = tok_embeddings:
+#     after token v the row of T1(v) scores ~ a * |e_v|^2 / rms(h), the row of T2(v) `runner` times that;
+#   * T1 is one cycle through the whole vocabulary (a permutation) laid out so that the walk from `start_a` reaches EOS as
+#     its len_a-th token; the walk from `start_b` carries BACK-EDGES (override rows scoring `back` x the successor's): at those
+#     steps the un-penalised arg-max is a token generated a few steps earlier, so with repetition_penalty 1.0 the stream
+#     loops until max_new_tokens, and with 1.5 (score / 1.5 for generated ids: transformers 4.45.2
+#     RepetitionPenaltyLogitsProcessor) it walks on and stops at an EOS override as its len_b-th token.
+PEAKED = dict(branch_shift=9, a=0.25, runner=0.7, back=1.2, noise_std=0.002, len_a=72, len_b=80,
+              back_at=(9, 17, 26, 34, 45, 58, 66), back_hop=4, runner_shift=40503, eos=92542, start_b=2000)
+
+
+def peaked_plan(vocab, start_a, seed=0, cfg=PEAKED):
+    """The walk tables of the peaked checkpoint.  Returns dict(t1, t2 (LongTensor[vocab]), overrides [(v, u, strength)],
+    chain_a, chain_b (ids each walk is BUILT to generate, EOS included), loop_b (what chain B's prompt generates without a
+    penalty: the first back-edge closes a cycle))."""
+    eos, start_b = cfg['eos'], cfg['start_b']
+    assert len({start_a, start_b, eos}) == 3
+    g = torch.Generator()
+    g.manual_seed(int(seed) * 7919 + 20251002)
+    order = [t for t in torch.randperm(vocab, generator=g).tolist() if t not in (start_a, start_b, eos)]
+    la, lb = cfg['len_a'], cfg['len_b']
+    seq = [start_a] + order[:la - 1] + [eos, start_b] + order[la - 1:]
+    assert len(seq) == vocab
+    seq_t = torch.tensor(seq, dtype=torch.long)
+    t1 = torch.empty(vocab, dtype=torch.long)
+    t1[seq_t] = torch.roll(seq_t, -1)
+    t2 = torch.empty(vocab, dtype=torch.long)
+    t2[seq_t] = torch.roll(seq_t, -cfg['runner_shift'])
+    pos_b = la + 1                                       # index of start_b in seq
+    z = seq[pos_b:pos_b + lb + 1]                        # z[0] = start_b, z[k] = k-th token of walk B
+    a = cfg['a']
+    overrides = [(z[k], z[k - cfg['back_hop']], cfg['back'] * a) for k in cfg['back_at']]
+    overrides.append((z[lb - 1], eos, cfg['back'] * a))
+    chain_a = seq[1:la + 1]
+    chain_b = z[1:lb] + [eos]
+    k0, hop = cfg['back_at'][0], cfg['back_hop']
+    cyc = z[k0 - hop:k0 + 1]
+    loop_b = z[1:k0 + 1] + [cyc[i % len(cyc)] for i in range(64)]
+    assert chain_a[-1] == eos and len(chain_a) == la and len(chain_b) == lb
+    return dict(t1=t1, t2=t2, overrides=overrides, chain_a=chain_a, chain_b=chain_b, loop_b=loop_b, start_b=start_b)
+
+
+def peaked_output_weight(dims: ModelDims, start_a, seed=0, cfg=PEAKED, dtype=torch.bfloat16):
+    """language_model.output.weight of the peaked checkpoint (CPU; ~5 GB of fp32 temporaries)."""
+    plan = peaked_plan(dims.vocab, start_a, seed, cfg)
+    name = 'language_model.output.weight'
+    E = make_tensor('language_model.model.tok_embeddings.weight', llm_keys(dims)['language_model.model.tok_embeddings.weight'],
+                    seed, 'cpu', torch.bfloat16).float()
+    W = _randn(name + '#peaked', (dims.vocab, dims.llm_hidden), cfg['noise_std'], seed, 'cpu', torch.float32)
+    W.index_add_(0, plan['t1'], E * cfg['a'])
+    W.index_add_(0, plan['t2'], E * (cfg['a'] * cfg['runner']))
+    for v, u, s in plan['overrides']:
+        W[u] += E[v] * s
+    return W.to(dtype)
+
+
+def iter_peaked_llm(dims: ModelDims, start_a, seed=0, cfg=PEAKED, device='cpu', dtype=torch.bfloat16):
+    """(key, tensor) over the language-model keys of the peaked checkpoint, in `llm_keys` order."""
+    scale = 2.0 ** -cfg['branch_shift']
+    for k, s in llm_keys(dims).items():
+        if k == 'language_model.output.weight':
+            yield k, peaked_output_weight(dims, start_a, seed, cfg, dtype).to(device)
+        elif k.endswith('attention.wo.weight') or k.endswith('feed_forward.w2.weight'):
+            yield k, make_tensor(k, s, seed, device, dtype) * scale
+        else:
+            yield k, make_tensor(k, s, seed, device, dtype)
+
+
+def peaked_prompt_embeds(n_vit_rows, n_ref_rows, hidden=4096, seed=0, dtype=torch.bfloat16):
+    """Stand-ins for extract_feature's rows and calli_align's pseudo tokens in the peaked run's prompt (CPU draw)."""
+    return (_randn('peaked.vit_embeds', (n_vit_rows, hidden), 0.05, seed, 'cpu', dtype),
+            _randn('peaked.reference_embeds', (n_ref_rows, hidden), 0.02, seed, 'cpu', dtype))

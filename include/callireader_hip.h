@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 5   /* 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 6   /* 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -48,6 +48,9 @@ typedef struct cr_model_desc {
 
 const char* cr_last_error(void);
 int cr_abi_version(void);
+/* sha256 (first 16 hex digits) of the .hip / .hpp sources and of this header the library was compiled from, set by
+ * callireader_amd/build.py (-DCR_BUILD_ID): lets a log prove which source tree a run used.  "unknown" for a hand build. */
+const char* cr_build_id(void);
 
 /* ---- lifetime & weights --------------------------------------------------------------------- */
 /* InternVLChatModel.__init__ (InternVL/modeling_internvl_chat.py:136-194) */
@@ -142,6 +145,11 @@ int cr_llm_prefill(cr_ctx* ctx, cr_kv* kv, int seq, const void* embeds, int S, f
  * last_logits [n,vocab] fp32 (may be NULL). */
 int cr_llm_prefill_batch(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const void* embeds, const int32_t* lens,
                          float penalty, float* last_logits, void* stream);
+/* Parity tooling: while `dst` is not NULL, every cr_llm_prefill / cr_llm_prefill_batch also copies rows [row0, row0 + rows) of the
+ * residual stream (row index into the concatenated prompt rows) into dst [llm_layers + 1][rows][4096] bf16 (device): slot 0 = the
+ * decoder stack's input, slot l + 1 = the output of InternLM2DecoderLayer l (InternVL/modeling_internlm2.py:621-681; what
+ * output_hidden_states=True collects at :916-918,965-967, before the final norm).  dst = NULL switches it off. */
+int cr_llm_hidden_probe(cr_ctx* ctx, void* dst, int row0, int rows);
 /* One greedy step for sequences seqs[0..n) (host array): embed each sequence's last generated id (or
  * force_tokens[i], device int64, when not NULL), run the decoder against the cache, append K/V, apply the
  * penalty, argmax, append the new id.  logits [n,vocab] fp32 raw (may be NULL).  Replaces one iteration of

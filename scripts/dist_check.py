@@ -22,7 +22,7 @@ dist.init_process_group(backend)
 
 IMG, REF = 8990, 8991
 PT, CT, NEW = 2, 5, 6                       # page tiles, char tiles per page (deliberately not divisible by world), new tokens
-n_pages = 3
+n_pages = int(os.environ.get('CR_DIST_PAGES', '3'))       # 11 with 8 ranks: ragged page ownership (2,2,2,1,...) and ragged tile shards (55 and 22 tiles over 8)
 dims = ModelDims.reduced(vit_layers=1, llm_layers=1, rs_depth=1, vocab=9000)
 sd = synthetic.make_state_dict(dims, seed=0)
 m = InternVLChatModel.from_state_dict(sd, dims, device=dev_idx, max_tokens=1024, max_pages=n_pages)
@@ -64,5 +64,15 @@ if rank == 0:
     single = run(list(range(n_pages)), v1, p1.reshape(-1, 3, dims.llm_hidden))
     ok = all(merged[p] == single[p] for p in range(n_pages)) and torch.equal(v1, vit_all)
     print('DIST_CHECK', 'OK' if ok else 'MISMATCH', merged, single, flush=True)
+    out = os.environ.get('CR_DIST_JSON')
+    if out:
+        import json
+        from callireader_amd.parallel import shard_counts
+        os.makedirs(os.path.dirname(out) or '.', exist_ok=True)
+        json.dump({'what': 'scripts/dist_check.py: tile shards + all-gather + round-robin page ownership against one process, ids per page',
+                   'world_size': world, 'backend': backend, 'visible_gpus': torch.cuda.device_count(), 'pages': n_pages,
+                   'pages_per_rank': [len(owned_pages(n_pages, world, r)) for r in range(world)],
+                   'char_tile_shards': shard_counts(n_pages * CT, world), 'page_tile_shards': shard_counts(n_pages * PT, world),
+                   'ids_equal_single_process': bool(ok), 'ids': {str(k): v for k, v in sorted(merged.items())}}, open(out, 'w'), indent=1)
 dist.barrier()
 dist.destroy_process_group()

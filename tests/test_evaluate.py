@@ -98,3 +98,26 @@ def test_full_page_report_sharded_over_ranks(tmp_path):
     for k in a['average']:
         assert abs(a['average'][k] - b['average'][k]) < 1e-12
     assert avg == b['average']
+
+
+def test_compare_fp8_report(tmp_path):
+    """--compare_fp8: the same pages scored twice (bf16, fp8 switches) -> per-page agreement and the F1 / NED deltas of the gate."""
+    pq = str(tmp_path / 'easy.parquet')
+    refs = ['君不见，黄河之水天上来！', '高堂明镜悲白发。', '朝如青丝暮成雪']
+    make_parquet(pq, refs)
+    args = (None, None, dict(max_new_tokens=8), '读出图中所有文字。', True, False, False, 1.0, False)
+    a, b = str(tmp_path / 'bf16.json'), str(tmp_path / 'fp8.json')
+    ev.test_full_page(pq, a, FakeModel(['君不见黄河之水天上来', '高堂明镜悲白发', '朝如青丝暮成雪']), *args, batch_pages=1)
+    ev.test_full_page(pq, b, FakeModel(['君不见黄河之水天上来', '高堂明镜白发', '朝如青丝暮成霜']), *args, batch_pages=1)
+    cmp = ev.compare_reports(json.load(open(a, encoding='utf-8'))['detailed'], json.load(open(b, encoding='utf-8'))['detailed'])
+    assert cmp['pages'] == 3 and cmp['identical_outputs'] == 1
+    assert abs(cmp['mean_ned_between_outputs'] - (0 + 1 / 7 + 1 / 7) / 3) < 1e-12
+    assert cmp['avg_f1_bf16'] == 1.0 and cmp['avg_ned_bf16'] == 0.0
+    assert cmp['delta_f1'] < 0 and abs(cmp['delta_ned'] - (1 / 7 + 1 / 7) / 3) < 1e-12
+
+
+def test_main_refuses_to_score_without_t2s(monkeypatch):
+    if ev.cc._cc is not None:
+        pytest.skip('opencc is installed here')
+    with pytest.raises(SystemExit, match='opencc'):
+        ev.main(['--data', '/nonexistent'])

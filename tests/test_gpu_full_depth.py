@@ -12,7 +12,7 @@ reference sits to exact arithmetic.
 Token bar: the HIP path's free-running greedy ids must equal the reference's.  A difference is only accepted at a step
 where the reference's own top-2 margin is below the measured logit difference bound (a tie the reference itself would
 resolve differently under any re-association), and then the test prints the step and that margin and walks on
-teacher-forced.  Everything measured is written to profiles/round2/full_depth_parity.json (gpurun_out/ on the GPU box
+teacher-forced.  Everything measured is written to profiles/round3/full_depth_parity.json (gpurun_out/ on the GPU box
 as well) so the numbers quoted in DESIGN.md have an artifact.
 """
 import json
@@ -45,8 +45,32 @@ def bits_to_f32(u16):
     return torch.from_numpy(u16.astype(np.int32) << 16).view(torch.float32)
 
 
+# Token bar.  A greedy pick that differs from the reference's is accepted ONLY as a measured near-tie:
+#   * the HIP pick must be one of the reference's own top-16 candidates of that step (its reference logit is then known);
+#   * gap = ref[ref_id] - ref[hip_id] (>= the reference's top-2 margin) must be covered by the logit differences MEASURED AT THOSE
+#     TWO IDS, gap <= |d(ref_id)| + |d(hip_id)| -- i.e. the two HIP logits straddle, nothing is excused by a row-wide bound;
+#   * each of the two differences must itself be within the reference's own bf16-vs-fp32 max |d| (the yardstick), and
+#   * gap <= TIE_CAP: every mismatch ever recorded on these weights sits at a reference margin <= 0.156 and every step with a
+#     margin >= 0.19 matches (profiles/round2/full_depth_parity.json), so 0.25 = 4 bf16 steps at |logit| 4..8 is the cap
+#     (round 2 excused up to 2 x the row's max |d| ~ 0.7).
+# Free-running token-exactness itself is demonstrated where the reference's margins allow it: tests/test_gpu_peaked.py.
+TIE_CAP = 0.25
+
+
+def check_near_tie(where, got, ref_id, hip_id, ref_logit_of, noise_abs):
+    assert hip_id in ref_logit_of, f'{where}: HIP picked {hip_id}, which is not among the reference\'s top-16 candidates'
+    gap = ref_logit_of[ref_id] - ref_logit_of[hip_id]
+    d_ref, d_hip = float(got[ref_id]) - ref_logit_of[ref_id], float(got[hip_id]) - ref_logit_of[hip_id]
+    rec = {'gap': gap, 'd_ref_id': d_ref, 'd_hip_id': d_hip}
+    print(f'  {where}: pick differs: reference gap {gap:.4f}, measured d(ref id) {d_ref:+.4f}, d(hip id) {d_hip:+.4f}')
+    assert gap <= abs(d_ref) + abs(d_hip) + 1e-6, (where, rec)
+    assert max(abs(d_ref), abs(d_hip)) <= noise_abs, (where, rec)
+    assert gap <= TIE_CAP, (where, rec)
+    return rec
+
+
 def _dump():
-    for d in (os.path.join(ROOT, 'profiles', 'round2'), os.path.join(ROOT, 'gpurun_out')):
+    for d in (os.path.join(ROOT, 'profiles', 'round3'), os.path.join(ROOT, 'gpurun_out')):
         try:
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, 'full_depth_parity.json'), 'w') as f:
@@ -131,9 +155,10 @@ def test_llm_32_layers_full_vocab_vs_reference(gold, engine):
     # (2) teacher-forced along the reference's ids: every step's logits against the reference's
     kv.reset(0)
     lg = engine.prefill(kv, 0, emb.cuda(), want_logits=True)
-    per_step, picks = [], []
+    per_step, picks, rows_kept = [], [], []
     for t in range(steps + 1):
         got, ref = lg.float().cpu().reshape(-1), ref_logits[t]
+        rows_kept.append(got)
         picked = kv.generated(0)[t]
         picks.append(picked)
         per_step.append({'rel_l2': rel_l2(got, ref), 'max_abs': float((got - ref).abs().max()),
@@ -156,10 +181,12 @@ def test_llm_32_layers_full_vocab_vs_reference(gold, engine):
     assert out['worst_rel_l2'] <= noise_l2, out['worst_rel_l2']
     assert out['worst_max_abs'] <= max(noise_abs, 0.12), out['worst_max_abs']
     # tokens: exact, or a reference near-tie (margin below the logit difference actually measured at that step)
+    top_ids, top_val = g['llm32.top16_ids'], g['llm32.top16_logits']
     for t, p in enumerate(per_step):
         if p['hip_id'] != p['ref_id']:
-            print(f'  greedy pick differs at step {t}: reference margin {p["ref_margin"]:.4f}, logit |d| bound {p["max_abs"]:.4f}')
-            assert p['ref_margin'] <= 2 * p['max_abs'], (t, p)
+            p['near_tie'] = check_near_tie(f'llm32 step {t}', rows_kept[t], p['ref_id'], p['hip_id'],
+                                           dict(zip(top_ids[t].tolist(), top_val[t].tolist())), noise_abs)
+    _dump()
     if first_div is None:
         assert free_ids == ref_ids
     else:
@@ -191,11 +218,46 @@ def test_llm_kv_rows_vs_reference(gold, engine):
     kv.free()
 
 
+def test_llm_layerwise_error_budget(gold, engine):
+    """Where the logit difference comes from: the residual stream before layer 0 and after each of the 32 layers (three prompt
+    rows), HIP against the reference's own hidden states (tests/golden/full_depth_layers.npz, scripts/make_golden_layers.py: forward
+    hooks on the reference's decoder layers), next to the reference's OWN bf16-vs-fp32 distance at the same layer.  Written to
+    profiles/round3/full_depth_parity.json (key llm32_layers); bound: at every layer the HIP path sits no further from the bf16
+    reference than the bf16 reference sits from its fp32 self."""
+    g, meta = gold
+    gl = np.load(os.path.join(ROOT, 'tests', 'golden', 'full_depth_layers.npz'))
+    rows = gl['layers.rows'].tolist()
+    ref = bits_to_f32(gl['layers.bf16_bits'])                   # [33][3][4096]
+    yard = gl['layers.ref_bf16_vs_fp32_rel_l2'].tolist()
+    S = meta['prompt_tokens']
+    gen = torch.Generator().manual_seed(meta['prompt_seed'])
+    emb = (torch.randn(1, S, 4096, generator=gen) * 0.02).to(torch.bfloat16)
+    probe = engine.hidden_probe(rows=S)
+    kv = engine.kv_alloc(1, 512)
+    try:
+        engine.prefill(kv, 0, emb.cuda())
+        torch.cuda.synchronize()
+        got = probe[:, rows, :].float().cpu()
+    finally:
+        engine.hidden_probe(None)
+        kv.free()
+    per = [{'after_layer': l, 'hip_vs_reference_rel_l2': rel_l2(got[l], ref[l]), 'reference_bf16_vs_fp32_rel_l2': yard[l],
+            'residual_rms': float(gl['layers.ref_rms'][l])} for l in range(ref.shape[0])]
+    RESULTS['llm32_layers'] = {'rows': rows, 'per_layer': per,
+                               'worst_ratio_to_yardstick': max(p['hip_vs_reference_rel_l2'] / max(p['reference_bf16_vs_fp32_rel_l2'], 1e-12) for p in per[1:])}
+    _dump()
+    for p in per:
+        print(f"  residual after layer {p['after_layer']:2d}: HIP vs reference {p['hip_vs_reference_rel_l2']:.3e}   reference bf16 vs fp32 {p['reference_bf16_vs_fp32_rel_l2']:.3e}")
+    assert per[0]['hip_vs_reference_rel_l2'] == 0.0              # the stack's input is the prompt itself
+    for p in per[1:]:
+        assert p['hip_vs_reference_rel_l2'] <= p['reference_bf16_vs_fp32_rel_l2'], p
+
+
 def test_llm_extra_prompts_token_agreement(gold, engine):
     """Two more prompts (64 and 513 tokens, 12 greedy steps each), teacher-forced along the reference's ids: per step the
     reference's top-16 logits and a stride-8 sample of the row are compared, and the greedy pick is counted."""
     g, meta = gold
-    noise_l2 = float(g['llm32.ref_bf16_vs_fp32_rel_l2'])
+    noise_l2, noise_abs = float(g['llm32.ref_bf16_vs_fp32_rel_l2']), float(g['llm32.ref_bf16_vs_fp32_max_abs'])
     summary = []
     for i, (seed, tokens, steps) in enumerate(meta['extra_prompts']):
         tag = f'llm32.extra{i}'
@@ -206,9 +268,10 @@ def test_llm_extra_prompts_token_agreement(gold, engine):
         strided = bits_to_f32(g[f'{tag}.logits_stride8_bf16_bits'])
         kv = engine.kv_alloc(1, 1024)
         lg = engine.prefill(kv, 0, emb.cuda(), want_logits=True)
-        rows = []
+        rows, kept = [], []
         for t in range(steps + 1):
             got = lg.float().cpu().reshape(-1)
+            kept.append(got)
             picked = kv.generated(0)[t]
             rows.append({'rel_l2_stride8': rel_l2(got[::8], strided[t]), 'max_abs_top16': float((got[top_ids[t]] - top_val[t]).abs().max()),
                          'max_abs_stride8': float((got[::8] - strided[t]).abs().max()),
@@ -224,8 +287,9 @@ def test_llm_extra_prompts_token_agreement(gold, engine):
         for t, r in enumerate(rows):
             assert r['rel_l2_stride8'] <= noise_l2, (tag, t, r)
             if r['ref_id'] != r['hip_id']:
-                print(f'  {tag} step {t}: pick differs, reference margin {r["ref_margin"]:.4f}, |d| on this row {r["max_abs_stride8"]:.4f}')
-                assert r['ref_margin'] <= 2 * max(r['max_abs_stride8'], r['max_abs_top16']), (tag, t, r)
+                r['near_tie'] = check_near_tie(f'{tag} step {t}', kept[t], r['ref_id'], r['hip_id'],
+                                               dict(zip(top_ids[t].tolist(), top_val[t].tolist())), noise_abs)
+        summary[-1]['differing'] = [{'step': t, **r} for t, r in enumerate(rows) if r['ref_id'] != r['hip_id']]
     RESULTS['llm32_extra'] = summary
     _dump()
     print('full-depth LLM, extra prompts:', json.dumps(summary))
@@ -276,9 +340,10 @@ def test_config1_example_page_end_to_end_vs_reference(gold, engine):
     steps = len(ref_ids) - 1
     kv = engine.kv_alloc(1, 3328)
     lg = engine.prefill(kv, 0, emb, want_logits=True)
-    rows = []
+    rows, kept = [], []
     for t in range(steps + 1):
         got = lg.float().cpu().reshape(-1)
+        kept.append(got)
         picked = kv.generated(0)[t]
         rows.append({'rel_l2_stride8': rel_l2(got[::8], strided[t]), 'max_abs_stride8': float((got[::8] - strided[t]).abs().max()),
                      'max_abs_top16': float((got[top_ids[t]] - top_val[t]).abs().max()), 'ref_id': ref_ids[t], 'hip_id': picked,
@@ -302,13 +367,13 @@ def test_config1_example_page_end_to_end_vs_reference(gold, engine):
     for t, r in enumerate(rows):
         assert r['rel_l2_stride8'] <= noise_llm, (t, r)
         if r['ref_id'] != r['hip_id']:
-            print(f'  config 1 step {t}: pick differs, reference margin {r["ref_margin"]:.4f}, |d| on this row {r["max_abs_stride8"]:.4f}')
-            assert r['ref_margin'] <= 2 * max(r['max_abs_stride8'], r['max_abs_top16']), (t, r)
+            r['near_tie'] = check_near_tie(f'config 1 step {t}', kept[t], r['ref_id'], r['hip_id'],
+                                           dict(zip(top_ids[t].tolist(), top_val[t].tolist())), float(g['llm32.ref_bf16_vs_fp32_max_abs']))
 
 
 def test_fp8_mfma_option_at_full_depth_is_recorded(gold, engine):
     """The fp8 matrix-core option (OFF by default) at full depth against the same reference vectors: recorded next to the bf16
-    numbers in profiles/round2/full_depth_parity.json.  Random-init weights are the unfavourable case (every fp8 linear adds ~5 %
+    numbers in profiles/round3/full_depth_parity.json.  Random-init weights are the unfavourable case (every fp8 linear adds ~5 %
     of independent relative noise and 24 / 32 layers of it accumulate); the assertions are sanity bounds, the gate on real weights
     is evaluate.py --type full_page."""
     g, meta = gold

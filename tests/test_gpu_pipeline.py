@@ -75,3 +75,56 @@ def test_borrowed_weights_compute_what_the_owner_computes(model):
     c = eng.prefill(eng.kv_alloc(1, 512), 0, emb, want_logits=True)
     torch.cuda.synchronize()
     assert torch.equal(a, c)
+
+
+def test_pipeline_caches_grow_only_when_idle(model):
+    """Batches that outgrow the pipeline's KV caches (1, 3, 5, 2 pages with caches that start at one page): a cache is regrown
+    only when its own turn comes -- never the one the worker thread is decoding from -- and every batch keeps its ids."""
+    bs = batches(5)
+    bs = [bs[1], bs[0], bs[2], bs[3]]
+    ref = [model.generate_pages(b, max_new_tokens=20, eos_token_id=None) for b in bs]
+    old = model.max_pages
+    model.max_pages = 1
+    try:
+        pipe = model.page_pipeline(max_new_tokens=20, eos_token_id=None, check_every=4)
+        outs = []
+        for b in bs:
+            prev = pipe.start(b)
+            if prev is not None:
+                outs.append(prev)
+        outs.append(pipe.finish())
+        assert [kv.n_seqs for kv in pipe.kvs] == [5, 3]
+        pipe.close()
+    finally:
+        model.max_pages = old
+    assert outs == ref
+
+
+def test_borrower_notices_that_the_owner_changed(model):
+    """cr_share_weights copies a snapshot of the owner's tensor map: once the owner builds fp8 copies, switches an fp8 option or
+    reloads, the borrower's stage entry points refuse to run until the weights are shared again."""
+    from callireader_amd.engine import Engine
+    from callireader_amd._binding import CalliReaderError
+    eng = model.engine
+    other = Engine(eng.dims, device=eng.device.index, max_pos=eng.max_pos)
+    other.share_weights_from(eng)
+    g = torch.Generator().manual_seed(11)
+    emb = (torch.randn(100, 4096, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    kv = eng.kv_alloc(2, 256)
+    a = other.prefill(kv, 0, emb, want_logits=True).clone()
+    eng.enable_fp8_decode(True)
+    try:
+        with pytest.raises(CalliReaderError, match='share again'):
+            other.prefill(kv, 1, emb)
+        with pytest.raises(CalliReaderError, match='share again'):
+            other.decode(kv, [0])
+    finally:
+        eng.enable_fp8_decode(False)
+    with pytest.raises(CalliReaderError, match='share again'):      # switching it off changes the owner's generation too
+        other.prefill(kv, 1, emb)
+    other.share_weights_from(eng)
+    b = other.prefill(kv, 1, emb, want_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    kv.free()
+    other.close()

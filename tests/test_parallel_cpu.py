@@ -1,4 +1,4 @@
-"""World-size-2 (and 3) gloo runs of the tile sharding + all-gather used by the N > 1 path (CPU, no GPU needed)."""
+"""World-size-2, 3 and 8 gloo runs of the tile sharding + all-gather used by the N > 1 path (CPU, no GPU needed)."""
 import os
 import socket
 
@@ -50,7 +50,7 @@ def _worker(rank, world, port, total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,total', [(2, 8), (2, 7), (3, 10), (2, 1)])
+@pytest.mark.parametrize('world,total', [(2, 8), (2, 7), (3, 10), (2, 1), (8, 64), (8, 61), (8, 5)])      # 8 ranks: even, ragged, and ranks with no rows at all
 def test_all_gather_rows_gloo(world, total):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
