@@ -290,6 +290,20 @@ int cr_op_attention(const void* q, const void* k, const void* v, void* o, const 
     p.o_bs = s[9]; p.o_rs = s[10]; p.o_hs = s[11];
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.kv_group = kv_group; p.q_pos0 = q_pos0;
     p.q_prescale = q_prescale; p.s_div = s_div;
+    if (!causal && head_dim == 64 && Sq == Sk && Sq > 256 && ((Sq - 1) & 127) == 0 && s_div == 1.0f && kv_group == 1) {
+        // the ViT layout takes attention_vit.hip, which wants scratch for the CLS query's partials: this test / profiling entry point
+        // keeps one grow-only buffer per process (stage entry points carve theirs out of the context's workspace)
+        static float* scratch = nullptr;
+        static size_t scratch_n = 0;
+        const size_t need = vit_attn_ws_floats(B, H, Sq);
+        if (need > scratch_n) {
+            if (scratch) hipFree(scratch);
+            scratch = nullptr; scratch_n = 0;
+            if (hipMalloc((void**)&scratch, need * 4) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "cr_op_attention: scratch");
+            scratch_n = need;
+        }
+        p.part_ml = scratch;
+    }
     int r = launch_flash_attn(p, head_dim, causal != 0, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_attention(d=%d) rejected or failed", head_dim);
     return CR_OK;

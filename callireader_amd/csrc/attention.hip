@@ -422,6 +422,7 @@ int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t strea
 int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_t stream) {
     if (p.Sq <= 0 || (p.Sk <= 0 && !p.sk_arr && !p.seg) || p.H <= 0 || p.B <= 0 || p.kv_group <= 0 || (p.seg && !causal)) return CR_ERR_ARG;
     if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7) || (p.o_rs & 3)) return CR_ERR_ARG;
+    if (vit_attn_supported(p, head_dim, causal)) return launch_vit_attn(p, stream);
     if (head_dim == 64) return causal ? launch_t<64, true>(p, stream) : launch_t<64, false>(p, stream);
     if (head_dim == 128) return causal ? launch_t<128, true>(p, stream) : launch_t<128, false>(p, stream);
     return CR_ERR_ARG;

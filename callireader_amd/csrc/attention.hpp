@@ -33,3 +33,9 @@ int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_
 // decode: Sq <= 32 query rows per (batch, head), non-causal over each sequence's own keys, split over the keys
 int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t stream);
 size_t attn_split_ws_floats(int B, int H, int Sq, int nsplit, int head_dim);
+
+// ViT layout (S = 1 + 128 n tokens, d = 64, no mask): attention_vit.hip.  launch_flash_attn takes this path by itself when
+// p.part_ml points at vit_attn_ws_floats(B, H, S) floats of scratch (the CLS query's partials) and the shape qualifies.
+bool vit_attn_supported(const AttnParams& p, int head_dim, bool causal);
+size_t vit_attn_ws_floats(int B, int H, int S);
+int launch_vit_attn(const AttnParams& p, hipStream_t stream);

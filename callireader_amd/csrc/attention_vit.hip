@@ -1,0 +1,359 @@
+// ViT attention for gfx950, specialised for the InternViT token layout: S = 1 + 128 n tokens (CLS + a whole number of 128-row
+// query blocks; 1025 = 1 + 8 * 128 at 448 x 448), d = 64, no mask, q * 2^-3 in bf16, scores rounded to bf16 before the fp32 softmax
+// (InternVL/modeling_intern_vit.py:215-232).  Same arithmetic and MFMA data flow as flash_attn_kernel<64, false> (attention.hip:
+// swapped K.Q^T with the query on the lane, S accumulators as the P.V operand, V through ds_read_b64_tr_b16, K/V tiles by LDS-DMA),
+// but the one odd token no longer costs a ninth, 1-row query block (11 % of the workgroups, three of four waves idle) and a
+// seventeenth, 1-key tile per block (6 % of every block's work):
+//   * the 1024 PATCH queries form 8 full blocks of 128 and sweep the 1024 PATCH keys as 16 full tiles of 64: no padding, no masks;
+//   * the CLS KEY enters each query's softmax as the INITIAL state instead of a tile: s0 = q . k_cls by 32 FMAs per lane, the
+//     reference point of the exponentials m = bf16(s0), row sum 1, O = v_cls -- so every tile of the sweep takes the lean softmax
+//     path (attention.hip) from the first one on; a score ~42 above that point in any lane falls back to the exact rescaling form;
+//   * the CLS QUERY is spread over all workgroups of its (tile, head): block b sweeps its key tiles in the rotated order
+//     2b+2, ..., 2b+1 (a softmax does not care; it also spreads the eight blocks' K/V fetches over the tiles), so its LAST two tiles
+//     are 2b and 2b+1 and are both still in LDS when the sweep ends; each of the four waves then takes one 32-key half of them for the
+//     CLS query (4 + 4 MFMAs, exact softmax) and writes an un-normalised partial (m, l, O[64]); vit_cls_combine_kernel merges the
+//     4n + 1 partials (the +1: the CLS key itself, by block 0) in index order, like the decode path's split combine.
+// Work per (tile, head): 8 x 16.6 tile-times instead of 9 x 17.
+#include <stdlib.h>
+
+#include "attention.hpp"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_bf16(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float hi_bf16(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+// round_bf16(x) as an fp32 value in ONE v_cvt_pk_bf16_f32 (0, x): the low half of the result is bf16(0)
+__device__ __forceinline__ float rbf1(float x) {
+    const f32x2_t v = {0.f, x};
+    return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)));
+}
+
+constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB, KS = 4, DB = 2, CPR = 8, RPI = 8, IPW = 2;
+__device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
+
+__global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    // XCD-aware order (attention.hip): the query blocks of one (tile, head) read their K/V through ONE L2
+    int qb, head, batch;
+    const int gx = gridDim.x;
+    {
+        const int gy = gridDim.y;
+        const int total = gx * gy * (int)gridDim.z;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * (int)blockIdx.z);
+        const int xcd = lin & 7, q = total >> 3, r = total & 7;
+        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        qb = pid % gx;
+        head = (pid / gx) % gy;
+        batch = pid / (gx * gy);
+    }
+    const int NT = 2 * gx;                                  // 64-key tiles of patch keys
+    const bf16* Qb = p.Q + (int64_t)batch * p.q_bs + (int64_t)head * p.q_hs;
+    const bf16* Kc = p.K + (int64_t)batch * p.k_bs + (int64_t)head * p.k_hs;         // row 0 = the CLS key
+    const bf16* Vc = p.V + (int64_t)batch * p.v_bs + (int64_t)head * p.v_hs;
+    const bf16* Kb = Kc + p.k_rs;                                                     // patch keys, zero-based
+    const bf16* Vb = Vc + p.v_rs;
+    const int qrow = 1 + qb * 128 + wave * 32 + l31;
+
+    // ---- Q fragment (B operand of K.Q^T): lane (query l31, half hh) holds Q[q][16ks + 8hh .. +7], times 2^-3 in bf16 ----
+    auto load_q = [&](int row, bf16x8* dst) {
+        const bf16* qp = Qb + (int64_t)row * p.q_rs + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            dst[ks] = *(const bf16x8*)(qp + ks * 16);
+            if (p.q_prescale != 1.0f) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) dst[ks][e] = f2bf(bf2f(dst[ks][e]) * p.q_prescale);
+            }
+        }
+    };
+    // q . k_cls over this lane's 32 of the 64 dimensions, both halves summed
+    auto dot_cls_key = [&](const bf16x8* qv) {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const bf16x8 k0 = *(const bf16x8*)(Kc + ks * 16 + hh * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) part = fmaf(bf2f(qv[ks][e]), bf2f(k0[e]), part);
+        }
+        return part + __shfl_xor(part, 32, 64);
+    };
+    bf16x8 qf[KS];
+    load_q(qrow, qf);
+
+    // ---- staging: one 32-bit per-lane byte offset for K and one for V (row r = lane / 8 of an 8-row piece, swizzled 16-byte chunk);
+    // the piece, the tile and the (batch, head) go into the instruction's scalar base.  LDS-DMA is issued from inline asm (M0 = LDS
+    // base, saved and restored inside the statement): hipcc orders every LDS read behind a __builtin_amdgcn_global_load_lds it knows
+    // to be in flight (s_waitcnt vmcnt(0) in front of the P.V reads: the NEXT tile's fill sat on this tile's critical path); its
+    // landing is waited for by hand, once, in front of the tile's closing barrier.
+    const int sr = lane / CPR, scp = lane % CPR;             // row r = 8 * piece + sr: kswz(r) sees the piece's parity (= ii), vswz(r) does not
+    unsigned k_voff[IPW];
+#pragma unroll
+    for (int ii = 0; ii < IPW; ii++) k_voff[ii] = (unsigned)(sr * (int)p.k_rs + ((scp ^ kswz(8 * ii + sr)) * 8)) * 2u;
+    const unsigned v_voff = (unsigned)(sr * (int)p.v_rs + ((scp ^ vswz(sr)) * 8)) * 2u;
+    auto dma16 = [&](const bf16* sbase, unsigned voff, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int ii = 0; ii < IPW; ii++) {
+            const int64_t row = (int64_t)kt * 64 + (wave * IPW + ii) * RPI;                 // scalar
+            const unsigned dst = smem_base + buf * (2 * TILE) + (wave * IPW + ii) * 1024;
+            dma16(Kb + row * p.k_rs, k_voff[ii], dst);
+            dma16(Vb + row * p.v_rs, v_voff, dst + TILE);
+        }
+    };
+    int kt = 2 * qb + 2;                                    // rotated sweep: ends on tiles 2qb, 2qb + 1
+    if (kt >= NT) kt -= NT;
+    stage(0, kt);
+
+    // ---- initial softmax state = the CLS key ----
+    f32x16 oacc[DB];
+    float m_run, l_run;
+    {
+        m_run = rbf1(dot_cls_key(qf));                      // its score, rounded to bf16 like every score: P = exp(0) = 1
+        l_run = hh == 0 ? 1.0f : 0.0f;                      // row sums are kept per half-wave and added at the end
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const bf16x4 v0 = *(const bf16x4*)(Vc + 32 * db + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; e++) oacc[db][4 * g4 + e] = bf2f(v0[e]);
+            }
+    }
+
+    // lane-constant pieces of the LDS addresses (attention.hip)
+    const int k_lane_off = l31 * ROWB;
+    const int k_sw = kswz(l31);
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int v_lane_row = 4 * hh + tq;
+    const int v_sw = vswz(v_lane_row);
+    const int v_clow = (g & 1) * 2 + (tp >> 1);
+    const int v_lane_off = v_lane_row * ROWB + (tp & 1) * 8;
+
+    // S^T block = K[32 keys] . Q^T: 4 MFMAs
+    auto qk32 = [&](const char* kbuf, int kb, const bf16x8* qv) {
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const bf16x8 kf = *(const bf16x8*)(kbuf + kb * 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv[ks], s, 0, 0, 0);
+        }
+        return s;
+    };
+    // O^T += V^T[32 keys] . P^T: 4 MFMAs; pk = the block's 8 packed bf16 pairs
+    auto pv32 = [&](const char* vbuf, int kb, const unsigned* pk, f32x16* o) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const u32x4_t pw = {pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int db = 0; db < DB; db++) {
+                const int chunk = ((db * 4) ^ v_sw) | v_clow;
+                const char* vp = vbuf + (kb * 32 + 16 * s) * ROWB + v_lane_off + chunk * 16;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp + 8 * ROWB));
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+    };
+
+    // one 32-key block of scores -> P (packed bf16 pairs) and the row-sum update.  Lean form (attention.hip): the reference point stays
+    // where the CLS key put it; per score one v_cvt_pk_bf16_f32 (0, s), one FMA, one v_exp_f32, half an add, half a v_cvt_pk.  A block
+    // sum >= 2^60 in any lane (a score ~42 above the reference point, or +inf) redoes the block in the exact form with the deferred
+    // rescale.  The packed words are made opaque where they are produced: otherwise hipcc keeps the 32 fp32 values across the join of
+    // the two forms and pays 33 v_mov per tile.
+    auto softmax32 = [&](const f32x16& sc, unsigned* pk) {
+        const float m2f = m_run * LOG2E;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2f));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2f));
+            q0 += p0; q1 += p1;
+            unsigned w = pack_bf16(p0, p1);
+            asm volatile("" : "+v"(w));
+            pk[j] = w;
+        }
+        const float qs = q0 + q1;
+        if (__builtin_expect(__all(qs < 1.152921504606846976e18f), 1)) { l_run += qs; return; }
+        float mraw = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; e++) mraw = fmaxf(mraw, sc[e]);
+        float mloc = rbf1(mraw);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m2 = m_new * LOG2E;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2));
+            psum += p0 + p1;
+            unsigned w = pack_bf16(p0, p1);
+            asm volatile("" : "+v"(w));
+            pk[j] = w;
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < NT; i++) {
+        const int cur = i & 1;
+        if (i + 1 < NT) {
+            kt = kt + 1 == NT ? 0 : kt + 1;
+            stage(cur ^ 1, kt);
+        }
+        const char* kbuf = smem + cur * (2 * TILE);
+        const char* vbuf = kbuf + TILE;
+        // K.Q^T of both 32-key blocks, then block by block softmax -> P.V, so that the matrix work of one block can run under the
+        // vector work of the other (S of block 1 under the softmax of block 0, P.V of block 0 under the softmax of block 1)
+        const f32x16 s0 = qk32(kbuf, 0, qf);
+        const f32x16 s1 = qk32(kbuf, 1, qf);
+        unsigned pk0[8], pk1[8];
+        softmax32(s0, pk0);
+        pv32(vbuf, 0, pk0, oacc);
+        softmax32(s1, pk1);
+        pv32(vbuf, 1, pk1, oacc);
+        // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- patch queries: normalise and store; lane (query, half) owns d = 32db + 8g4 + 4hh + 0..3 ----
+    {
+        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = f2bf(oacc[db][4 * g4 + e] * inv);
+                *(bf16x4*)(op + 32 * db + 8 * g4) = o;
+            }
+    }
+
+    // ---- the CLS query: this wave's 32 keys of the block's last two tiles (still in LDS: tile 2qb in buffer 0, 2qb + 1 in buffer 1)
+    load_q(0, qf);                                          // every lane column holds the same query
+    const int nsplit = 4 * gx + 1;
+    const int64_t prow = ((int64_t)batch * p.H + head) * nsplit;
+    {
+        const char* kbuf = smem + (wave >> 1) * (2 * TILE);
+        const int kb = wave & 1;
+        const f32x16 s = qk32(kbuf, kb, qf);
+        float mraw = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; e++) mraw = fmaxf(mraw, s[e]);
+        float m = rbf1(mraw);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float m2 = m * LOG2E;
+        unsigned pk[8];
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(s[2 * j]), LOG2E, -m2));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(s[2 * j + 1]), LOG2E, -m2));
+            l += p0 + p1;
+            pk[j] = pack_bf16(p0, p1);
+        }
+        l += __shfl_xor(l, 32, 64);
+        f32x16 oc[DB];
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) oc[db][e] = 0.f;
+        pv32(kbuf + TILE, kb, pk, oc);
+        if (l31 == 0) {
+            const int64_t row = prow + qb * 4 + wave;
+            if (hh == 0) { p.part_ml[row * 2] = m; p.part_ml[row * 2 + 1] = l; }
+            float* po = p.part_o + row * D + 4 * hh;
+#pragma unroll
+            for (int db = 0; db < DB; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+                    *(f32x4*)(po + 32 * db + 8 * g4) = f32x4{oc[db][4 * g4], oc[db][4 * g4 + 1], oc[db][4 * g4 + 2], oc[db][4 * g4 + 3]};
+        }
+    }
+    if (qb == 0 && wave == 0) {                             // ... and the CLS key itself: a one-key partial, P = 1
+        const float s0 = rbf1(dot_cls_key(qf));
+        if (l31 == 0) {
+            const int64_t row = prow + 4 * gx;
+            if (hh == 0) { p.part_ml[row * 2] = s0; p.part_ml[row * 2 + 1] = 1.0f; }
+            float* po = p.part_o + row * D + 4 * hh;
+#pragma unroll
+            for (int db = 0; db < DB; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const bf16x4 v0 = *(const bf16x4*)(Vc + 32 * db + 8 * g4 + 4 * hh);
+                    *(f32x4*)(po + 32 * db + 8 * g4) = f32x4{bf2f(v0[0]), bf2f(v0[1]), bf2f(v0[2]), bf2f(v0[3])};
+                }
+        }
+    }
+}
+
+// O[cls][d] = sum_s exp(m_s - M) O_s[d] / sum_s exp(m_s - M) l_s over the (tile, head)'s partials, in index order (reproducible)
+__global__ __launch_bounds__(64) void vit_cls_combine_kernel(const AttnParams p, int nsplit) {
+    const int head = blockIdx.x, batch = blockIdx.y, d = threadIdx.x;
+    const int64_t base = ((int64_t)batch * p.H + head) * nsplit;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; s++) M = fmaxf(M, p.part_ml[(base + s) * 2]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < nsplit; s++) {
+        const float w = __expf(p.part_ml[(base + s) * 2] - M);
+        L += w * p.part_ml[(base + s) * 2 + 1];
+        acc += w * p.part_o[(base + s) * D + d];
+    }
+    p.O[(int64_t)batch * p.o_bs + (int64_t)head * p.o_hs + d] = f2bf(acc / L);
+}
+
+}  // namespace
+
+bool vit_attn_supported(const AttnParams& p, int head_dim, bool causal) {
+    const char* e = getenv("CR_VIT_ATTN");                // A/B aid: CR_VIT_ATTN=0 keeps the generic kernel (read per call: a bench flips it in one process)
+    const bool off = e && e[0] == '0';
+    return !off && head_dim == 64 && !causal && p.Sq == p.Sk && p.Sq > 256 && ((p.Sq - 1) & 127) == 0 && p.s_div == 1.0f && p.kv_group == 1 &&
+           !p.seq_map && !p.sk_arr && !p.seg && p.part_ml && (p.q_rs & 7) == 0 && (p.k_rs & 7) == 0 && (p.v_rs & 7) == 0 &&
+           (p.o_rs & 3) == 0 && (p.q_hs & 7) == 0 && (p.k_hs & 7) == 0 && (p.v_hs & 3) == 0 && (p.o_hs & 3) == 0;
+}
+
+size_t vit_attn_ws_floats(int B, int H, int S) { return (size_t)B * H * (4 * ((S - 1) / 128) + 1) * (64 + 2); }
+
+int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 2 * TILE;
+    static std::atomic<uint64_t> attr_done{0};
+    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS)) return CR_ERR_HIP;
+    const int nb = (p.Sq - 1) / 128;
+    AttnParams q = p;
+    q.part_o = p.part_ml + (size_t)p.B * p.H * (4 * nb + 1) * 2;       // one allocation: [m, l] pairs, then the O partials
+    hipLaunchKernelGGL(vit_attn_kernel, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
+    hipLaunchKernelGGL(vit_cls_combine_kernel, dim3(p.H, p.B), dim3(64), 0, stream, q, 4 * nb + 1);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}

@@ -60,6 +60,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
     bf16* f = ar.take<bf16>((size_t)M * FF);
     float* hs = ar.take<float>((size_t)M);          // fp8 matrix-core path: one scale per LayerNorm row
     float* fs = ar.take<float>((size_t)M);          // ... and per row of fc1's e4m3 output
+    float* apart = ar.take<float>(vit_attn_ws_floats(T, 16, TOK));     // attention_vit.hip: the CLS query's partials
 
     const bf16* patch_w = W(c, "derived.patch_w");
     const bf16* patch_b = W(c, "vision_model.embeddings.patch_embedding.bias");
@@ -105,6 +106,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         ap.o_bs = (int64_t)TOK * C1; ap.o_rs = C1; ap.o_hs = 64;
         ap.B = T; ap.H = 16; ap.Sq = TOK; ap.Sk = TOK; ap.kv_group = 1; ap.q_pos0 = 0;
         ap.q_prescale = 0.125f; ap.s_div = 1.0f;
+        ap.part_ml = apart;
         if (launch_flash_attn(ap, 64, false, st) != CR_OK) return cr_fail(CR_ERR_HIP, "vit attention launch failed");
         CR_TRY(gemm(c, EPI_LS_RES, h, C1, pw, C1, x, C1, pb, ls1, x, C1, M, C1, C1, 0, st));
 
@@ -131,7 +133,7 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
 
 static size_t vit_ws_bytes(int T) {
     const size_t M = (size_t)T * TOK;
-    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + M * 8 + 8192;
+    return ((size_t)T * 1024 * KPAD + M * C1 + M * C3 + M * FF) * 2 + M * 8 + vit_attn_ws_floats(T, 16, TOK) * 4 + 8192;
 }
 
 static size_t project_ws_bytes(int T) { return (size_t)T * 256 * 4096 * 4 + (size_t)T * 256 * 4 + 8192; }   // a, b, row scales
