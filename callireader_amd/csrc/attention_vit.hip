@@ -16,6 +16,8 @@
 // Work per (tile, head): 8 x 16.6 tile-times instead of 9 x 17.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "attention.hpp"
 
 namespace {
@@ -40,6 +42,7 @@ constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB, KS = 4, DB = 2, CPR = 8, RPI
 __device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
+template <bool ILV>
 __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -118,25 +121,8 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
             dma16(Vb + row * p.v_rs, v_voff, dst + TILE);
         }
     };
-    int kt = 2 * qb + 2;                                    // rotated sweep: ends on tiles 2qb, 2qb + 1
-    if (kt >= NT) kt -= NT;
-    stage(0, kt);
-
-    // ---- initial softmax state = the CLS key ----
     f32x16 oacc[DB];
     float m_run, l_run;
-    {
-        m_run = rbf1(dot_cls_key(qf));                      // its score, rounded to bf16 like every score: P = exp(0) = 1
-        l_run = hh == 0 ? 1.0f : 0.0f;                      // row sums are kept per half-wave and added at the end
-#pragma unroll
-        for (int db = 0; db < DB; db++)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const bf16x4 v0 = *(const bf16x4*)(Vc + 32 * db + 8 * g4 + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; e++) oacc[db][4 * g4 + e] = bf2f(v0[e]);
-            }
-    }
 
     // lane-constant pieces of the LDS addresses (attention.hip)
     const int k_lane_off = l31 * ROWB;
@@ -177,25 +163,25 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
         }
     };
 
-    // one 32-key block of scores -> P (packed bf16 pairs) and the row-sum update.  Lean form (attention.hip): the reference point stays
-    // where the CLS key put it; per score one v_cvt_pk_bf16_f32 (0, s), one FMA, one v_exp_f32, half an add, half a v_cvt_pk.  A block
-    // sum >= 2^60 in any lane (a score ~42 above the reference point, or +inf) redoes the block in the exact form with the deferred
-    // rescale.  The packed words are made opaque where they are produced: otherwise hipcc keeps the 32 fp32 values across the join of
-    // the two forms and pays 33 v_mov per tile.
-    auto softmax32 = [&](const f32x16& sc, unsigned* pk) {
-        const float m2f = m_run * LOG2E;
+    // one 32-key block of scores -> P (packed bf16 pairs) and the row-sum update, lean form (attention.hip): the reference point
+    // stays where the CLS key put it; per score one v_cvt_pk_bf16_f32 (0, s), one FMA, one v_exp_f32, half an add, half a v_cvt_pk.
+    // No branch, no rescale inside the sweep: P is bf16 (fp32's exponent range) and O, l are fp32, so scores up to ~88 above the
+    // reference point are still exact relative arithmetic; what lies beyond shows as a non-finite or > 2^100 row sum at the END of the
+    // sweep, and the whole block then repeats the sweep in the exact rescaling form (exact_sweep below).  A per-tile check with an
+    // in-loop fallback made hipcc copy the 32 accumulators twice per tile (40 v_mov_b64).
+    auto softmax32 = [&](const f32x16& sc, unsigned* pk, float m2f) {
         float q0 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2f));
             const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2f));
             q0 += p0; q1 += p1;
-            unsigned w = pack_bf16(p0, p1);
-            asm volatile("" : "+v"(w));
-            pk[j] = w;
+            pk[j] = pack_bf16(p0, p1);
         }
-        const float qs = q0 + q1;
-        if (__builtin_expect(__all(qs < 1.152921504606846976e18f), 1)) { l_run += qs; return; }
+        l_run += q0 + q1;
+    };
+    // the same block in the exact form: running maximum, rescale of O and l when it grows (only exact_sweep uses it)
+    auto softmax32_exact = [&](const f32x16& sc, unsigned* pk) {
         float mraw = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; e++) mraw = fmaxf(mraw, sc[e]);
@@ -211,9 +197,7 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
             const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2));
             const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2));
             psum += p0 + p1;
-            unsigned w = pack_bf16(p0, p1);
-            asm volatile("" : "+v"(w));
-            pk[j] = w;
+            pk[j] = pack_bf16(p0, p1);
         }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -221,34 +205,118 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
     };
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int i = 0; i < NT; i++) {
-        const int cur = i & 1;
-        if (i + 1 < NT) {
-            kt = kt + 1 == NT ? 0 : kt + 1;
-            stage(cur ^ 1, kt);
-        }
-        const char* kbuf = smem + cur * (2 * TILE);
-        const char* vbuf = kbuf + TILE;
-        // K.Q^T of both 32-key blocks, then block by block softmax -> P.V, so that the matrix work of one block can run under the
-        // vector work of the other (S of block 1 under the softmax of block 0, P.V of block 0 under the softmax of block 1)
-        const f32x16 s0 = qk32(kbuf, 0, qf);
-        const f32x16 s1 = qk32(kbuf, 1, qf);
-        unsigned pk0[8], pk1[8];
-        softmax32(s0, pk0);
-        pv32(vbuf, 0, pk0, oacc);
-        softmax32(s1, pk1);
-        pv32(vbuf, 1, pk1, oacc);
-        // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them
+    auto init_state = [&]() {                               // the CLS key as the initial softmax state
+        m_run = rbf1(dot_cls_key(qf));                      // its score, rounded to bf16 like every score: P = exp(0) = 1
+        l_run = hh == 0 ? 1.0f : 0.0f;                      // row sums are kept per half-wave and added at the end
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const bf16x4 v0 = *(const bf16x4*)(Vc + 32 * db + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; e++) oacc[db][4 * g4 + e] = bf2f(v0[e]);
+            }
+    };
+    // one sweep over the NT key tiles in the rotated order; ends with tiles 2qb / 2qb + 1 in LDS buffers 0 / 1
+    auto sweep = [&](auto exact) {
+        int kt = 2 * qb + 2;
+        if (kt >= NT) kt -= NT;
+        stage(0, kt);
+        init_state();
+        const float m2f = m_run * LOG2E;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < NT; i++) {
+            const int cur = i & 1;
+            if (i + 1 < NT) {
+                kt = kt + 1 == NT ? 0 : kt + 1;
+                stage(cur ^ 1, kt);
+            }
+            const char* kbuf = smem + cur * (2 * TILE);
+            const char* vbuf = kbuf + TILE;
+            unsigned pk0[8], pk1[8];
+            if (decltype(exact)::value || !ILV) {
+                const f32x16 s0 = qk32(kbuf, 0, qf);
+                const f32x16 s1 = qk32(kbuf, 1, qf);
+                if (decltype(exact)::value) softmax32_exact(s0, pk0); else softmax32(s0, pk0, m2f);
+                pv32(vbuf, 0, pk0, oacc);
+                if (decltype(exact)::value) softmax32_exact(s1, pk1); else softmax32(s1, pk1, m2f);
+                pv32(vbuf, 1, pk1, oacc);
+            } else {
+                // Hand-interleaved tile: an MFMA runs 32 cycles on the matrix pipe after issue, and a wave issues in order, so every
+                // MFMA of block 1's K.Q^T and of block 0's P.V is followed by a QUARTER of the other block's softmax (4 scores: 16
+                // vector instructions) inside a scheduling fence -- the vector work runs under the matrix work instead of after it:
+                //   A: S0 = K0.Q^T (4 MFMAs)             B: 4 x { S1 += K1[ks].Q^T[ks] ; softmax quarter ks of S0 }
+                //   C: 4 x { O += V0[i].P0[i] ; softmax quarter i of S1 }          D: O += V1.P1 (4 MFMAs)
+                bf16x8 kf0[KS], kf1[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    kf0[ks] = *(const bf16x8*)(kbuf + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
+                    kf1[ks] = *(const bf16x8*)(kbuf + 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);                     // all eight fragment reads in flight before the first MFMA waits for one
+                f32x16 s0, s1;
+#pragma unroll
+                for (int e = 0; e < 16; e++) { s0[e] = 0.f; s1[e] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                float q0 = 0.f, q1 = 0.f;
+                auto quarter = [&](const f32x16& sc, unsigned* pk, int q) {
+#pragma unroll
+                    for (int j = 2 * q; j < 2 * q + 2; j++) {
+                        const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2f));
+                        const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2f));
+                        q0 += p0; q1 += p1;
+                        pk[j] = pack_bf16(p0, p1);
+                    }
+                };
+                auto vfrag = [&](int kb, int sidx, int db) {
+                    const int chunk = ((db * 4) ^ v_sw) | v_clow;
+                    const char* vp = vbuf + (kb * 32 + 16 * sidx) * ROWB + v_lane_off + chunk * 16;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp + 8 * ROWB));
+                    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                };
+                auto pfrag = [&](const unsigned* pk, int sidx) {
+                    const u32x4_t pw = {pk[4 * sidx], pk[4 * sidx + 1], pk[4 * sidx + 2], pk[4 * sidx + 3]};
+                    return __builtin_bit_cast(bf16x8, pw);
+                };
+                bf16x8 vf[4];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+                    quarter(s0, pk0, ks);
+                    vf[ks] = vfrag(0, ks >> 1, ks & 1);                 // P.V operands of block 0, read a step ahead
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    oacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pfrag(pk0, i >> 1), oacc[i & 1], 0, 0, 0);
+                    quarter(s1, pk1, i);
+                    vf[i] = vfrag(1, i >> 1, i & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                l_run += q0 + q1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) oacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pfrag(pk1, i >> 1), oacc[i & 1], 0, 0, 0);
+            }
+            // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    sweep(std::false_type{});
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    // (NaN compares false: a non-finite sum takes the exact sweep as well; the vote is workgroup-uniform, the sweeps share barriers)
+    if (__syncthreads_or(!(l_tot < 1.2676506002282294e30f))) {
+        sweep(std::true_type{});
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
     }
 
     // ---- patch queries: normalise and store; lane (query, half) owns d = 32db + 8g4 + 4hh + 0..3 ----
     {
-        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        const float inv = 1.0f / l_tot;
         bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
 #pragma unroll
         for (int db = 0; db < DB; db++)
@@ -348,12 +416,15 @@ size_t vit_attn_ws_floats(int B, int H, int S) { return (size_t)B * H * (4 * ((S
 
 int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * TILE;
-    static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS)) return CR_ERR_HIP;
+    static std::atomic<uint64_t> attr_done{0}, attr_done2{0};
+    const char* e = getenv("CR_VIT_ATTN");                // A/B aid: 2 = the tile body as the compiler orders it (no hand interleave)
+    const bool plain = e && e[0] == '2';
+    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel<true>, LDS) || !cr_dyn_lds_once(attr_done2, (const void*)vit_attn_kernel<false>, LDS)) return CR_ERR_HIP;
     const int nb = (p.Sq - 1) / 128;
     AttnParams q = p;
     q.part_o = p.part_ml + (size_t)p.B * p.H * (4 * nb + 1) * 2;       // one allocation: [m, l] pairs, then the O partials
-    hipLaunchKernelGGL(vit_attn_kernel, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
+    if (plain) hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
+    else hipLaunchKernelGGL(vit_attn_kernel<true>, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
     hipLaunchKernelGGL(vit_cls_combine_kernel, dim3(p.H, p.B), dim3(64), 0, stream, q, 4 * nb + 1);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }

@@ -155,10 +155,15 @@ __global__ __launch_bounds__(256) void denorm_kernel(const bf16* __restrict__ x,
 }
 
 int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* bias,
-         const bf16* res, int64_t ldr, int M, int N, int K, hipStream_t st) {
+         const bf16* res, int64_t ldr, int M, int N, int K, hipStream_t st, bool latent_rows = false) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.res = res; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K;
+    // The latents' GEMMs have 3 rows per tile.  Up to 64 rows the dispatcher would pick the weight-streaming kernel, whose waves split K
+    // (another summation order than the tiled kernels'): a tile's pseudo tokens would then depend on how many tiles share its call -- 7
+    // tiles per rank against 55 in one process flipped a near-tie in scripts/dist_check.py at 8 ranks.  Pinned to the tiled kernel, whose
+    // K order is the same in all its forms, a tile's result is the same in every batch and on every rank count.
+    if (latent_rows && M <= 64) p.kernel = 128;
     return ctx_gemm(c, epi, p, st);
 }
 
@@ -230,13 +235,13 @@ static int resample_chunk(cr_ctx* c, const bf16* x, int T, bf16* out, hipStream_
         CR_TRY(ln(x, kv_in, nmw, nmb, (int64_t)T * 256, 256, NKV, 0, st));
         CR_TRY(ln(learns, kv_in, nlw, nlb, R, NQ, NKV, 256, st));
         CR_TRY(ln(learns, lnl, nlw, nlb, R, 0, 0, 0, st));
-        CR_TRY(gemm(c, EPI_STORE, lnl, D, wq, D, q, INNER, nullptr, nullptr, 0, (int)R, INNER, D, st));              // :35
+        CR_TRY(gemm(c, EPI_STORE, lnl, D, wq, D, q, INNER, nullptr, nullptr, 0, (int)R, INNER, D, st, true));        // :35
         CR_TRY(gemm(c, EPI_STORE, kv_in, D, wkv, D, kv, 2 * INNER, nullptr, nullptr, 0, T * NKV, 2 * INNER, D, st));  // :39
         hipLaunchKernelGGL(perceiver_attn_kernel, dim3(T, HEADS), dim3(64), 0, st, q, kv, ao, 0.125f);
-        CR_TRY(gemm(c, EPI_RES, ao, INNER, wo, INNER, learns, D, nullptr, learns, D, (int)R, D, INNER, st));          // :51 + :97
+        CR_TRY(gemm(c, EPI_RES, ao, INNER, wo, INNER, learns, D, nullptr, learns, D, (int)R, D, INNER, st, true));    // :51 + :97
         CR_TRY(ln(learns, lnl, fw0, fb0, R, 0, 0, 0, st));                                                         // FeedForward :134
-        CR_TRY(gemm(c, EPI_GELU, lnl, D, fw1, D, ff, 4 * D, fb1, nullptr, 0, (int)R, 4 * D, D, st));
-        CR_TRY(gemm(c, EPI_RES, ff, 4 * D, fw3, 4 * D, learns, D, fb3, learns, D, (int)R, D, 4 * D, st));             // :98
+        CR_TRY(gemm(c, EPI_GELU, lnl, D, fw1, D, ff, 4 * D, fb1, nullptr, 0, (int)R, 4 * D, D, st, true));
+        CR_TRY(gemm(c, EPI_RES, ff, 4 * D, fw3, 4 * D, learns, D, fb3, learns, D, (int)R, D, 4 * D, st, true));       // :98
     }
     const bf16 *nw = W(c, "resampler.norm.weight"), *nb = W(c, "resampler.norm.bias");
     if (!nw || !nb) return CR_ERR_STATE;

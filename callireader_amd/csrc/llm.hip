@@ -270,9 +270,12 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const bf16* __restric
 }
 
 int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
-         int M, int N, int K, hipStream_t st) {
+         int M, int N, int K, hipStream_t st, bool prefill_rows = false) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.res = res; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
+    // a prompt row's result must not depend on what it is prefilled with: prompts of <= 64 rows in all stay on the tiled kernel, whose K
+    // order is that of every longer prefill (the weight-streaming kernel the dispatcher would pick splits K over its waves)
+    if (prefill_rows && M <= 64) p.kernel = 128;
     return ctx_gemm(c, epi, p, st);
 }
 
@@ -359,7 +362,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         else if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st)
                                : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st));
         else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st)
-                        : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st));
+                        : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st, !decode));
         hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
                            decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens,
                            (const float*)(sliced ? pbuf : nullptr), s_qkv);
@@ -394,13 +397,13 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                 CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_o, w.s_o, x, D, nullptr, M, D, D, st, x, D));
             } else {
                 CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st)
-                          : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st));
+                          : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st, !decode));
             }
             CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         }
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_SWIGLU, h, hs, w.q_13, w.s_13, act, ff, nullptr, M, 2 * ff, D, st));
         else CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st)
-                       : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st));
+                       : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st, !decode));
         if (sliced) {
             CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, act, ff, w.q_2, w.s_2, pbuf, D, nullptr, 0, M, D, ff, st)
                       : gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st));
@@ -416,7 +419,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_2, w.s_2, x, D, nullptr, M, D, ff, st, x, D));
         } else {
             CR_TRY(f8 ? gemm8(c, EPI_RES, act, ff, w.q_2, w.s_2, x, D, x, D, M, D, ff, st)
-                      : gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st));
+                      : gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st, !decode));
         }
         CR_TRY(probe(l + 1));
     }

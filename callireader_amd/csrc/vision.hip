@@ -15,9 +15,12 @@
 static constexpr int VIT_CHUNK = 255;  // 255*1025 rows = 1021 row-tiles of 256: x4 column tiles = 15.95 rounds of 256 CUs; per-launch fixed costs (cold
                                        // start, tail) spread over 4x the work of round 1's 63-tile chunks: 1.3 % on 510 tiles; operands stay < 4 GiB
 // Chunks of 16k-1 tiles (127, ..., 31, 15) put ceil(rows/256) * {4,12,16} GEMM tiles just under a whole number of
-// 256-CU rounds; e.g. 32 tiles are run as 31 + 1 (129 row-tiles -> 125: the 129th held 32 rows and cost a round).
+// 256-CU rounds.  Up to 64 tiles go as ONE chunk: rows = 1024 T + T, so the T rows past the last multiple of 256 are exactly
+// what the dispatcher hands to the one-wave tail kernel (gemm.hip: launch_gemm_tail, <= 64 rows) -- 32 tiles (BASELINE config 2)
+// used to run as 31 + 1, and the 1-tile chunk's 24 x 7 launches of almost nothing cost more than the 32nd tile's work.
 static int next_chunk(int remaining) {
     static const int cap = [] { const char* e = getenv("CR_VIT_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 && v < VIT_CHUNK ? v : VIT_CHUNK; }();   // tuning aid
+    if (remaining <= 64 && remaining <= cap) return remaining;
     for (int c : {255, 191, 127, 111, 95, 79, 63, 47, 31, 15}) if (c <= cap && remaining >= c) return c;
     return remaining < cap ? remaining : cap;
 }

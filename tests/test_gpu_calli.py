@@ -44,6 +44,23 @@ def test_resampler_single_tile(setup):
     assert rel_l2(out.float().cpu(), setup['rs'][:1].float()) <= 1.5e-2
 
 
+def test_tile_results_do_not_depend_on_the_batch(setup):
+    """A tile's pseudo tokens must be the same whether it is resampled alone, in a rank's shard of 7, or with every other tile of
+    a batch (the 8-rank flow of scripts/dist_check.py shards 55 tiles as 7 + ... + 6): bit for bit, through resampler, VQ and
+    de-normalisation.  30 tiles = 90 latent rows crosses the 64-row line where the GEMM dispatcher changes kernel class."""
+    eng = setup['eng']
+    g = torch.Generator().manual_seed(17)
+    feats = (torch.randn(30, 256, 4096, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    whole = eng.resample(feats)
+    for step in (1, 7, 21, 22):
+        parts = torch.cat([eng.resample(feats[i:i + step]) for i in range(0, 30, step)])
+        assert torch.equal(parts, whole), f'resampler output depends on the batch (chunks of {step})'
+    idx = eng.vq(whole)
+    assert torch.equal(torch.cat([eng.vq(whole[i:i + 7]) for i in range(0, 30, 7)]), idx)
+    back = eng.denorm(whole, idx)
+    assert torch.equal(torch.cat([eng.denorm(whole[i:i + 7], idx[i:i + 7]) for i in range(0, 30, 7)]), back)
+
+
 def test_vq_planted_and_random(setup):
     o, sd = setup['oracle'], setup['sd']
     table = sd['normed_emb.weight']
