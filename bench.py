@@ -116,6 +116,54 @@ def cpu_baseline():
                        f'{NEW_TOKENS} new tokens) = {page_s:.0f} s/page; sample wall {time.time() - t_all:.0f} s')}
 
 
+def measure_traffic(pages=16):
+    """roofline.traffic measured IN THIS RUN: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need
+    separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots), at `pages` pages x 2 new tokens -- the same tiled-GEMM launch shapes
+    as the 64-page step (255-tile ViT chunks, 16-page prefill batches) in a quarter of the dispatches (counter mode does not survive
+    the full step).  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 as that guide prescribes for gfx950; these counters sit on the L2's
+    fabric side, Infinity-Cache hits included.  Returns (bytes per launch of the M >= 1024 tiled class, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return None, 'rocprofv3 not found'
+    args = ['--steps', '1', '--warmup', '0', '--pages', str(pages), '--new-tokens', '2', '--no-cpu-baseline', '--no-vit-extra', '--no-pipeline', '--no-traffic']
+    work = tempfile.mkdtemp(prefix='cr_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    sums = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(work, counter)
+            r = subprocess.run([prof, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + args,
+                               cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f'rocprofv3 --pmc {counter} failed (rc {r.returncode}): ' + r.stdout.decode(errors='replace')[-300:]
+            vals = []
+            for row in csv.DictReader(open(files[0])):
+                k = row['Kernel_Name']
+                if row['Counter_Name'] != counter or not ('gemm256_kernel' in k or 'gemm128_kernel' in k):
+                    continue
+                if 'gemm128' in k and int(row['Grid_Size']) < 8 * 8 * 256:
+                    continue                                  # M < 1024: not in the roofline class
+                vals.append(float(row['Counter_Value']))
+            if not vals:
+                return None, f'no tiled-GEMM rows in the {counter} pass'
+            sums[counter] = (sum(vals), len(vals))
+    except Exception as e:                                    # a profiler problem must not cost the bench line
+        return None, f'traffic pass failed: {e}'
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fb = 2 * sums['FETCH_SIZE'][0] * 1024 / sums['FETCH_SIZE'][1]
+    wb = sums['WRITE_SIZE'][0] * 1024 / sums['WRITE_SIZE'][1]
+    return fb + wb, (f'measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of this script at {pages} pages x 2 new tokens: '
+                     f'the 64-page step\'s tiled-GEMM launch shapes), {sums["FETCH_SIZE"][1]} launches; bytes per launch on the L2 fabric side (Infinity-Cache hits '
+                     f'included) = (2*FETCH_SIZE + WRITE_SIZE)*1024: reads {fb / 1e9:.2f} GB + writes {wb / 1e9:.2f} GB')
+
+
 def cpu_baseline_full(threads):
     """Calibration of the sample above: the oracle on ONE WHOLE page of the bench's shape -- 107 tiles through
     24 ViT layers + mlp1, 96 of them through the 4-layer resampler + VQ + de-normalisation, splice, 3164-token prefill through 32
@@ -186,6 +234,7 @@ def main():
                     help='weak: --pages per GPU per step whatever N; strong: --total-pages per step over all GPUs (BASELINE config 4 as written: 64 pages over 8 GPUs = 8 per GPU)')
     ap.add_argument('--total-pages', type=int, default=64, help='pages per step over all ranks with --scaling strong')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc child runs behind roofline.traffic (N = 1 only; the committed measurement is quoted instead)')
     ap.add_argument('--cpu-baseline', choices=('sample', 'full'), default='sample',
                     help='sample: bounded sample extrapolated to one page (default, ~15 s); full: the oracle on ONE WHOLE example-shaped page (107 tiles, 24 + 4 + 32 layers, '
                          '3164-token prefill, 8 decode steps; minutes of host time and ~25 GB of host memory), printed next to the extrapolation')
@@ -576,7 +625,12 @@ def main():
             del embeds
             # fp8 on the matrix cores, also an EXTRA: the same step with the norm-fed / quantised linears of the ViT, the projector
             # and the LLM prefill in e4m3 x e4m3 (v_mfma_f32_16x16x128_f8f6f4) and the decode on e4m3 weights
-            eng.enable_fp8_mfma(True)
+            eng.enable_fp8_mfma(True, level=1)
+            step(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(); torch.cuda.synchronize()
+            dt_step8_l1 = time.perf_counter() - t0             # level 1 alone: norm-fed linears only, decode in bf16
+            eng.enable_fp8_mfma(True, level=2)
             eng.enable_fp8_decode(True)
             step(); torch.cuda.synchronize()
             st8 = [0.0]
@@ -587,15 +641,36 @@ def main():
             dt_step8 = time.perf_counter() - t0
             eng.enable_fp8_mfma(False)
             eng.enable_fp8_decode(False)
-            result['fp8_mfma'] = {'what': 'one whole step (one batch at a time) with cr_enable_fp8_mfma + cr_enable_fp8_decode: ViT QKV / fc1 / fc2, mlp1[1] and all four LLM '
+            result['fp8_mfma'] = {'what': 'one whole step (one batch at a time) with cr_enable_fp8_mfma level 2 + cr_enable_fp8_decode: ViT QKV / fc1 / fc2, mlp1[1] and all four LLM '
                                           'prefill linears multiply e4m3 x e4m3 (per-row activation scales from the norm kernels, from fc1\'s own epilogue under a '
                                           'LayerNorm-derived bound, or from a quantiser pass; per-row weight scales; fp32 accumulation); ViT proj, attention, '
                                           'resampler, VQ, KV cache stay bf16: an option, not the headline',
-                                  'pages_per_s': round(n_pages / dt_step8, 4), 'ms_per_step': round(dt_step8 * 1e3, 1), 'speedup_vs_bf16_step_one_batch_at_a_time': round((seq_ms if seq_ms else ms_per_step) / (dt_step8 * 1e3), 3),
+                                  'pages_per_s': round(n_pages / dt_step8, 4), 'ms_per_step': round(dt_step8 * 1e3, 1),
+                                  'level1_only_pages_per_s': round(n_pages / dt_step8_l1, 4),
+                                  'accuracy': 'NOT parity-preserving on random-init weights (profiles/round3/full_depth_parity.json: fp8_mfma_full_depth; peaked_streams.json: fp8); the gate on a real checkpoint is evaluate.py --compare_fp8', 'speedup_vs_bf16_step_one_batch_at_a_time': round((seq_ms if seq_ms else ms_per_step) / (dt_step8 * 1e3), 3),
                                   'visual_ms': round((st8[1] - st8[0]) * 1e3, 1), 'prefill_ms': round((st8[2] - st8[1]) * 1e3, 1),
                                   'parity': 'tests/test_gpu_fp8_mfma.py: exact on e4m3-representable data; model-level difference to the bf16 path stated there'}
+        if not args.no_traffic and args.pages >= 16 and args.scaling == 'weak':
+            # HBM-side bytes per launch of the dominant kernel class, measured on THIS box in THIS run (untimed, after everything else)
+            try:
+                pipe = None
+                del model, eng
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+            except NameError:
+                pass
+            tb, note = measure_traffic()
+            if tb is not None:
+                result['roofline']['traffic'] = tb
+                result['roofline']['traffic_note'] = note
+            else:
+                result['roofline']['traffic_note'] += f' [live measurement unavailable: {note}]'
         if not args.no_cpu_baseline:
-            del model
+            try:
+                del model
+            except NameError:
+                pass
             result['cpu_baseline'] = cpu_baseline()
             if args.cpu_baseline == 'full':
                 result['cpu_baseline']['full_page'] = cpu_baseline_full(result['cpu_baseline']['cores'])

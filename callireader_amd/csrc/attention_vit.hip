@@ -42,7 +42,6 @@ constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB, KS = 4, DB = 2, CPR = 8, RPI
 __device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
-template <bool ILV>
 __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -234,73 +233,17 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
             }
             const char* kbuf = smem + cur * (2 * TILE);
             const char* vbuf = kbuf + TILE;
+            // K.Q^T of both 32-key blocks, then block by block softmax -> P.V: hipcc runs block 0's P.V MFMAs under block 1's softmax.
+            // (Measured null, same run: a hand interleave -- every MFMA of S1 and of P.V0 fenced together with a quarter of the other
+            // block's softmax -- 0.389 ms against 0.388 for this form; per wave-tile the vector pipe carries ~520 cycles of issue, the
+            // matrix pipe 512, and three waves per SIMD overlap them only to ~1290.)
+            const f32x16 s0 = qk32(kbuf, 0, qf);
+            const f32x16 s1 = qk32(kbuf, 1, qf);
             unsigned pk0[8], pk1[8];
-            if (decltype(exact)::value || !ILV) {
-                const f32x16 s0 = qk32(kbuf, 0, qf);
-                const f32x16 s1 = qk32(kbuf, 1, qf);
-                if (decltype(exact)::value) softmax32_exact(s0, pk0); else softmax32(s0, pk0, m2f);
-                pv32(vbuf, 0, pk0, oacc);
-                if (decltype(exact)::value) softmax32_exact(s1, pk1); else softmax32(s1, pk1, m2f);
-                pv32(vbuf, 1, pk1, oacc);
-            } else {
-                // Hand-interleaved tile: an MFMA runs 32 cycles on the matrix pipe after issue, and a wave issues in order, so every
-                // MFMA of block 1's K.Q^T and of block 0's P.V is followed by a QUARTER of the other block's softmax (4 scores: 16
-                // vector instructions) inside a scheduling fence -- the vector work runs under the matrix work instead of after it:
-                //   A: S0 = K0.Q^T (4 MFMAs)             B: 4 x { S1 += K1[ks].Q^T[ks] ; softmax quarter ks of S0 }
-                //   C: 4 x { O += V0[i].P0[i] ; softmax quarter i of S1 }          D: O += V1.P1 (4 MFMAs)
-                bf16x8 kf0[KS], kf1[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    kf0[ks] = *(const bf16x8*)(kbuf + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
-                    kf1[ks] = *(const bf16x8*)(kbuf + 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
-                }
-                __builtin_amdgcn_sched_barrier(0);                     // all eight fragment reads in flight before the first MFMA waits for one
-                f32x16 s0, s1;
-#pragma unroll
-                for (int e = 0; e < 16; e++) { s0[e] = 0.f; s1[e] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                float q0 = 0.f, q1 = 0.f;
-                auto quarter = [&](const f32x16& sc, unsigned* pk, int q) {
-#pragma unroll
-                    for (int j = 2 * q; j < 2 * q + 2; j++) {
-                        const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2f));
-                        const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2f));
-                        q0 += p0; q1 += p1;
-                        pk[j] = pack_bf16(p0, p1);
-                    }
-                };
-                auto vfrag = [&](int kb, int sidx, int db) {
-                    const int chunk = ((db * 4) ^ v_sw) | v_clow;
-                    const char* vp = vbuf + (kb * 32 + 16 * sidx) * ROWB + v_lane_off + chunk * 16;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp + 8 * ROWB));
-                    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                };
-                auto pfrag = [&](const unsigned* pk, int sidx) {
-                    const u32x4_t pw = {pk[4 * sidx], pk[4 * sidx + 1], pk[4 * sidx + 2], pk[4 * sidx + 3]};
-                    return __builtin_bit_cast(bf16x8, pw);
-                };
-                bf16x8 vf[4];
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
-                    quarter(s0, pk0, ks);
-                    vf[ks] = vfrag(0, ks >> 1, ks & 1);                 // P.V operands of block 0, read a step ahead
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    oacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pfrag(pk0, i >> 1), oacc[i & 1], 0, 0, 0);
-                    quarter(s1, pk1, i);
-                    vf[i] = vfrag(1, i >> 1, i & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                l_run += q0 + q1;
-#pragma unroll
-                for (int i = 0; i < 4; i++) oacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pfrag(pk1, i >> 1), oacc[i & 1], 0, 0, 0);
-            }
+            if (decltype(exact)::value) softmax32_exact(s0, pk0); else softmax32(s0, pk0, m2f);
+            pv32(vbuf, 0, pk0, oacc);
+            if (decltype(exact)::value) softmax32_exact(s1, pk1); else softmax32(s1, pk1, m2f);
+            pv32(vbuf, 1, pk1, oacc);
             // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -416,15 +359,12 @@ size_t vit_attn_ws_floats(int B, int H, int S) { return (size_t)B * H * (4 * ((S
 
 int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * TILE;
-    static std::atomic<uint64_t> attr_done{0}, attr_done2{0};
-    const char* e = getenv("CR_VIT_ATTN");                // A/B aid: 2 = the tile body as the compiler orders it (no hand interleave)
-    const bool plain = e && e[0] == '2';
-    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel<true>, LDS) || !cr_dyn_lds_once(attr_done2, (const void*)vit_attn_kernel<false>, LDS)) return CR_ERR_HIP;
+    static std::atomic<uint64_t> attr_done{0};
+    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS)) return CR_ERR_HIP;
     const int nb = (p.Sq - 1) / 128;
     AttnParams q = p;
     q.part_o = p.part_ml + (size_t)p.B * p.H * (4 * nb + 1) * 2;       // one allocation: [m, l] pairs, then the O partials
-    if (plain) hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
-    else hipLaunchKernelGGL(vit_attn_kernel<true>, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
+    hipLaunchKernelGGL(vit_attn_kernel, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
     hipLaunchKernelGGL(vit_cls_combine_kernel, dim3(p.H, p.B), dim3(64), 0, stream, q, 4 * nb + 1);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }

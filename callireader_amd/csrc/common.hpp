@@ -88,6 +88,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float erf_abs = 1.0f - s * e;
     return (x * 0.5f) * (1.0f + copysignf(erf_abs, x));
 }
+// The same function on a PAIR: every multiply / FMA / add is one packed instruction (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: IEEE
+// results identical to the scalar forms, so each component is bit for bit gelu_erf of its input; rcp and exp2 have no packed form).
+// 17 of the 21 issue slots halve: worth a quarter of the vector work of the fc1 / mlp1 epilogues (scripts/ubench/valu_issue.hip: a
+// packed fp32 op issues in ~1.4x the slot of a plain one and does two).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 t = ax * 0.70710678118654752440f;
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.29046997f, 0.29046997f}, t, f32x2{1.0f, 1.0f});
+    const f32x2 u = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 s = {1.3864057f, 1.3864057f};
+    s = __builtin_elementwise_fma(s, u, f32x2{-2.8561068f, -2.8561068f});
+    s = __builtin_elementwise_fma(s, u, f32x2{3.3568153f, 3.3568153f});
+    s = __builtin_elementwise_fma(s, u, f32x2{-1.7148181f, -1.7148181f});
+    s = __builtin_elementwise_fma(s, u, f32x2{0.73626f, 0.73626f});
+    s = __builtin_elementwise_fma(s, u, f32x2{0.0914439f, 0.0914439f});
+    s = s * u;
+    const f32x2 a = t * (t * -1.4426950408889634f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 erf_abs = f32x2{1.0f, 1.0f} - s * e;
+    const f32x2 sg = {copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1])};
+    return (x * 0.5f) * (f32x2{1.0f, 1.0f} + sg);
+}
 // 16 fp32 values times `inv` -> 16 e4m3 bytes (OCP e4m3fn, round to nearest even, saturating): one 16-byte store
 __device__ __forceinline__ void store16_e4m3(unsigned char* dst, const float* y, float inv) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;

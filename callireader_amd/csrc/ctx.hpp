@@ -27,7 +27,8 @@ struct cr_ctx {
                                         // null stream (which cannot be captured); implicitly ordered with it
     uint64_t weight_gen = 0;            // bumped by cr_load_weight / cr_finalize: captured graphs hold weight pointers
     bool fp8_decode = false;            // cr_enable_fp8_decode: batched decode streams e4m3 copies of the LLM's linear weights (half the bytes)
-    bool fp8_mfma = false;              // cr_enable_fp8_mfma: the norm-fed linears of the ViT, the projector and the LLM prefill run e4m3 x e4m3 on the matrix cores
+    int fp8_mfma = 0;                   // cr_enable_fp8_mfma level: 1 = the norm-fed linears of the ViT, the projector and the LLM prefill run e4m3 x e4m3 on the
+                                        // matrix cores; 2 = also the linears whose input no norm produces (ViT fc2 via fc1's e4m3 epilogue, LLM wo / w2 via a quantiser pass)
     bf16* probe_dst = nullptr;          // cr_llm_hidden_probe: [layers + 1][probe_rows][4096] rows of the residual stream of the next prefills
     int probe_row0 = 0, probe_rows = 0;
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)

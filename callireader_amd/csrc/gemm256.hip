@@ -106,8 +106,13 @@ __device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&b
         if (EPI == EPI_GELU || EPI == EPI_LS_RES) {          // bf16(acc + bias) is a value of its own before the next op
             round_pair_bf16(x[0], x[1], x[0], x[1]);
             round_pair_bf16(x[2], x[3], x[2], x[3]);
+            if (EPI == EPI_GELU) {                            // pairs: packed fp32 math (common.hpp: gelu_erf2), the same bits per element
+                const f32x2 g0 = gelu_erf2(f32x2{x[0], x[1]}), g1 = gelu_erf2(f32x2{x[2], x[3]});
+                x[0] = g0[0]; x[1] = g0[1]; x[2] = g1[0]; x[3] = g1[1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) x[e] = EPI == EPI_GELU ? gelu_erf(x[e]) : x[e] * scale_f[j][e];
+                for (int e = 0; e < 4; e++) x[e] = x[e] * scale_f[j][e];
+            }
         }
         const bf16x4 o = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
         *(bf16x4*)(buf + r * 128 + (((j * 4 + g) ^ r) << 3)) = o;

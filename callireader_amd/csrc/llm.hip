@@ -355,7 +355,8 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
         // prefill on the fp8 matrix-core path: both norms emit e4m3 rows + scales, wqkv and w1|w3 take them (gemm256 F8)
-        const bool m8 = any8 && w.q_qkv && w.s_qkv && w.q_13 && w.s_13 && w.q_o && w.s_o && w.q_2 && w.s_2;
+        const bool m8 = any8 && w.q_qkv && w.s_qkv && w.q_13 && w.s_13;
+        const bool m8all = m8 && c->fp8_mfma >= 2 && w.q_o && w.s_o && w.q_2 && w.s_2;      // level 2: wo and w2 as well (their inputs take a quantiser pass)
         if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         const bool f8 = decode && M <= 64 && c->fp8_decode && w.q_qkv && w.s_qkv && w.q_o && w.s_o && w.q_13 && w.s_13 && w.q_2 && w.s_2;
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_STORE, h, hs, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, M, QKV, D, st));
@@ -392,7 +393,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                       : gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st));
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_o, M, w.fn, h, c->d.rms_eps, st));
         } else {
-            if (m8) {       // wo and w2 take activations no norm produced: one quantiser pass each (row maximum, then the e4m3 row)
+            if (m8all) {    // wo and w2 take activations no norm produced: one quantiser pass each (row maximum, then the e4m3 row)
                 hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, ao, (int64_t)D, D, a8, hs);
                 CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_o, w.s_o, x, D, nullptr, M, D, D, st, x, D));
             } else {
@@ -414,7 +415,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                 next_norm = wn.an;
             }
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_2, M, next_norm, h, c->d.rms_eps, st));
-        } else if (m8) {
+        } else if (m8all) {
             hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, act, (int64_t)ff, ff, a8, hs);
             CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_2, w.s_2, x, D, nullptr, M, D, ff, st, x, D));
         } else {
@@ -504,7 +505,7 @@ int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float*
 
 int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_mfma: null context");
-    if (!enable) { if (c->fp8_mfma) c->weight_gen++; c->fp8_mfma = false; return CR_OK; }      // captured decode graphs are keyed on weight_gen
+    if (!enable) { if (c->fp8_mfma) c->weight_gen++; c->fp8_mfma = 0; return CR_OK; }      // captured decode graphs are keyed on weight_gen
     if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
@@ -539,7 +540,7 @@ int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     for (const std::string& nm : names) CR_TRY(build_fp8_copy(c, nm, 256, st));
     CR_HIP(hipGetLastError());
     CR_HIP(hipStreamSynchronize(st));
-    c->fp8_mfma = true;
+    c->fp8_mfma = enable >= 2 ? 2 : 1;
     c->weight_gen++;
     return CR_OK;
 }

@@ -93,7 +93,8 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         const DevTensor *q_f1 = WTopt(c, "fp8." + p + "mlp.fc1.weight"), *s_f1 = WTopt(c, "fp8s." + p + "mlp.fc1.weight");
         const DevTensor *q_f2 = WTopt(c, "fp8." + p + "mlp.fc2.weight"), *s_f2 = WTopt(c, "fp8s." + p + "mlp.fc2.weight");
         const DevTensor* bnd = WTopt(c, "fp8b." + p + "mlp.fc1.weight");
-        const bool m8 = c->fp8_mfma && q_qkv && s_qkv && q_f1 && s_f1 && q_f2 && s_f2 && bnd;
+        const bool m8 = c->fp8_mfma && q_qkv && s_qkv && q_f1 && s_f1;
+        const bool m8all = m8 && c->fp8_mfma >= 2 && q_f2 && s_f2 && bnd;      // level 2: fc1 hands fc2 e4m3 rows straight from its epilogue
 
         NormParams np{};
         np.in = x; np.ld_in = C1; np.out = h; np.ld_out = C1; np.rows = M; np.eps = c->d.vit_ln_eps;
@@ -114,9 +115,13 @@ static int vit_chunk(cr_ctx* c, const bf16* px, int T, bf16* x, hipStream_t st) 
         CR_TRY(gemm(c, EPI_LS_RES, h, C1, pw, C1, x, C1, pb, ls1, x, C1, M, C1, C1, 0, st));
 
         np.gamma = n2w; np.beta = n2b;
-        if (m8) { np.next_scale = fs; np.next_bound = (const float*)bnd->ptr; }
+        if (m8all) { np.next_scale = fs; np.next_bound = (const float*)bnd->ptr; }
         CR_TRY(launch_layernorm(np, C1, 0, st));
-        if (m8) {
+        if (m8 && !m8all) {
+            // level 1: fc1 (its input is LayerNorm 2's e4m3 row) multiplies e4m3 x e4m3 and writes bf16; fc2 stays bf16
+            CR_TRY(ctx_gemm_f8(c, EPI_GELU, h, hs, q_f1, s_f1, f, FF, f1b, M, FF, C1, st));
+            CR_TRY(gemm(c, EPI_LS_RES, f, FF, f2w, FF, x, C1, f2b, ls2, x, C1, M, C1, FF, 0, st));
+        } else if (m8all) {
             // fc1 in e4m3, its GELU output written as e4m3 rows (scale = the bound LayerNorm 2 derived), fc2 in e4m3 on those rows
             GemmParams g1{};
             g1.A = h; g1.lda = C1; g1.W = (const bf16*)q_f1->ptr; g1.ldw = C1; g1.C = f; g1.ldc = FF; g1.bias = f1b; g1.M = M; g1.N = FF; g1.K = C1;

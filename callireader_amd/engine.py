@@ -93,10 +93,11 @@ class Engine:
         B.check(B.lib.cr_enable_fp8_decode(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_decode')
 
     # ---- vision ----
-    def enable_fp8_mfma(self, on=True):
-        """cr_enable_fp8_mfma: norm-fed linears (ViT QKV / fc1, mlp1[1], LLM prefill wqkv / w1|w3) multiply e4m3 x e4m3 on the matrix
-        cores; OFF by default (the reference's arithmetic is bf16)."""
-        B.check(B.lib.cr_enable_fp8_mfma(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_mfma')
+    def enable_fp8_mfma(self, on=True, level=1):
+        """cr_enable_fp8_mfma.  level 1: norm-fed linears (ViT QKV / fc1, mlp1[1], LLM prefill wqkv / w1|w3) multiply e4m3 x e4m3 on the
+        matrix cores; level 2: also ViT fc2 and the prefill's wo / w2.  OFF by default (the reference's arithmetic is bf16); a throughput
+        option whose accuracy only a real checkpoint can price (evaluate.py --compare_fp8)."""
+        B.check(B.lib.cr_enable_fp8_mfma(self._h, (2 if level >= 2 else 1) if on else 0, _stream()), 'cr_enable_fp8_mfma')
 
     def _chk_pixels(self, px):
         if px.dim() != 4:

@@ -202,7 +202,8 @@ def main(argv=None):
     parser.add_argument('--params', type=str, default='./params')
     parser.add_argument('--batch_pages', type=int, default=16, help='pages sent through the engine together')
     parser.add_argument('--fp8_decode', action='store_true', help='BASELINE config 5: e4m3 weights for the batched decode (cr_enable_fp8_decode)')
-    parser.add_argument('--fp8_mfma', action='store_true', help='BASELINE config 5: e4m3 x e4m3 matrix-core linears in the ViT / projector / prefill (cr_enable_fp8_mfma)')
+    parser.add_argument('--fp8_mfma', type=int, nargs='?', const=1, default=0, choices=(0, 1, 2),
+                        help='BASELINE config 5: e4m3 x e4m3 matrix-core linears (cr_enable_fp8_mfma): 1 = the norm-fed linears of the ViT / projector / prefill, 2 = also ViT fc2 and the prefill\'s wo / w2')
     parser.add_argument('--compare_fp8', action='store_true', help='run every file twice -- bf16, then with --fp8_decode / --fp8_mfma (both when neither is given) -- and '
                                                                    'write full_page_<level>_fp8_vs_bf16.json: identical outputs, NED between them, F1 / NED deltas')
     parser.add_argument('--allow_no_t2s', action='store_true', help='run without opencc (responses stay unconverted: scores not comparable with the reference\'s)')
@@ -231,11 +232,11 @@ def main(argv=None):
     model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16, max_pages=args.batch_pages, device=local).eval().cuda()
     want_mfma, want_dec = args.fp8_mfma, args.fp8_decode
     if args.compare_fp8 and not (want_mfma or want_dec):
-        want_mfma = want_dec = True
+        want_mfma, want_dec = 1, True
 
     def fp8(on):
         if want_mfma:
-            model.engine.enable_fp8_mfma(on)
+            model.engine.enable_fp8_mfma(on, level=want_mfma)
         if want_dec:
             model.engine.enable_fp8_decode(on)
     if not args.compare_fp8:

@@ -87,14 +87,15 @@ def main(argv=None):
     parser.add_argument('--params', type=str, default='./params')
     parser.add_argument('--boxes', type=str, default=None, help='labelme-style JSON with ordered character boxes')
     parser.add_argument('--fp8_decode', action='store_true', help='e4m3 weights for the decode (cr_enable_fp8_decode; off by default: the reference computes in bf16)')
-    parser.add_argument('--fp8_mfma', action='store_true', help='e4m3 x e4m3 matrix-core linears in the ViT / projector / prefill (cr_enable_fp8_mfma; off by default)')
+    parser.add_argument('--fp8_mfma', type=int, nargs='?', const=1, default=0, choices=(0, 1, 2),
+                        help='e4m3 x e4m3 matrix-core linears (cr_enable_fp8_mfma; off by default; a throughput option, not parity-preserving): 1 = the norm-fed linears of the ViT / projector / prefill, 2 = also ViT fc2 and the prefill\'s wo / w2')
     args = parser.parse_args(argv)
     if not isinstance(args.tgt, str):
         raise ValueError(f'The target should a string, not a instance of {type(args.tgt)}!')
     from .tokenization_internlm2 import InternLM2Tokenizer
     model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16).eval().cuda()
     if args.fp8_mfma:
-        model.engine.enable_fp8_mfma(True)
+        model.engine.enable_fp8_mfma(True, level=args.fp8_mfma)
     if args.fp8_decode:
         model.engine.enable_fp8_decode(True)
     # the engine's own reader of tokenizer.model (+ tokenizer_config.json / added_tokens.json): the reference's

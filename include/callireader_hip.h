@@ -166,13 +166,17 @@ int cr_llm_decode(cr_ctx* ctx, cr_kv* kv, const int32_t* seqs, int n, const int6
  * the fp32 sum.  Activations, KV cache, prefill and everything visual stay bf16.  enable == 0 switches back (copies kept).
  * Call after cr_finalize; re-run it after reloading weights. */
 int cr_enable_fp8_decode(cr_ctx* ctx, int enable, void* stream);
-/* fp8 on the matrix cores (same standing: an option, OFF by default).  enable != 0: the linears whose input is a norm's output --
- * QKV and fc1 of every ViT layer, mlp1's first linear, wqkv and w1|w3 of every LLM layer in PREFILL -- get the e4m3 copy + row
- * scale above, the norm kernel in front of each writes the normalised row as e4m3 with one fp32 scale per row
- * (max|y| / 448 over the bf16-rounded row) instead of bf16, and the 256x256 tiled kernel multiplies e4m3 x e4m3 with
- * v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulation, twice the bf16 rate), applying ascale[m] * wscale[n] to the finished sum before the
- * bias and the rest of the epilogue.  proj / fc2 / wo / w2, attention, the residual stream, the KV cache and decode stay as they
- * are.  Call after cr_finalize; re-run it after reloading weights. */
+/* fp8 on the matrix cores (same standing: an option, OFF by default; a THROUGHPUT option -- e4m3 keeps 3 mantissa bits, every such
+ * linear adds ~5 % of relative noise to its output, and whether the transcription survives that is what evaluate.py --compare_fp8 measures
+ * on a real checkpoint; nothing here is claimed to preserve the reference's tokens).
+ * enable = 1: the linears whose input is a norm's output -- QKV and fc1 of every ViT layer, mlp1's first linear, wqkv and w1|w3 of every
+ *   LLM layer in PREFILL -- get the e4m3 copy + row scale above, the norm kernel in front of each writes the normalised row as e4m3 with
+ *   one fp32 scale per row (max|y| / 448 over the bf16-rounded row) instead of bf16, and the 256x256 tiled kernel multiplies e4m3 x e4m3
+ *   with v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulation, twice the bf16 rate), applying ascale[m] * wscale[n] to the finished sum before
+ *   the bias and the rest of the epilogue.  proj / fc2 / wo / w2, attention, the residual stream, the KV cache and decode stay bf16.
+ * enable = 2: additionally the linears whose input no norm produces: ViT fc2 (fc1's epilogue writes its GELU output as e4m3 rows under a
+ *   LayerNorm-derived bound) and the LLM's wo / w2 in prefill (one quantiser pass over their input each).
+ * enable = 0 switches back (copies kept).  Call after cr_finalize; re-run it after reloading weights. */
 int cr_enable_fp8_mfma(cr_ctx* ctx, int enable, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------------- */

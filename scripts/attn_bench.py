@@ -18,9 +18,9 @@ o = torch.zeros(Bn, S, H * D, device='cuda', dtype=torch.bfloat16)
 C3, C1 = 3 * H * D, H * D
 run_vit = lambda: E.op_attention(qkv, qkv[:, :, C1:], qkv[:, :, 2 * C1:], o, [S * C3, C3, D, S * C3, C3, D, S * C3, C3, D, S * C1, C1, D], Bn, H, S, S, D, q_prescale=0.125)
 # interleaved rounds in ONE process: attention_vit.hip (CLS peeled off, 8 x 16 full tiles) against the generic kernel (9 x 17)
-res = {'vit': [], 'vit-plain': [], 'generic': []}
+res = {'vit': [], 'generic': []}
 for rnd in range(5):
-    for name, flag in (('vit', '1'), ('vit-plain', '2'), ('generic', '0')):
+    for name, flag in (('vit', '1'), ('generic', '0')):
         os.environ['CR_VIT_ATTN'] = flag
         res[name].append(timeit(run_vit))
 os.environ['CR_VIT_ATTN'] = '1'

@@ -173,7 +173,8 @@ def test_fc1_writes_e4m3_rows_under_the_layernorm_bound(E):
     print(f'fc1 -> e4m3 under the bound: the median row uses {used:.3f} of the scale ({-torch.log2(torch.tensor(used)).item():.1f} of e4m3\'s 15 binades given up)')
 
 
-def test_vit_and_projector_fp8_mfma_against_bf16():
+@pytest.mark.parametrize('level', [1, 2])
+def test_vit_and_projector_fp8_mfma_against_bf16(level):
     """Two ViT layers + mlp1 at full width.  Per e4m3 operand the relative rounding error is up to 2^-4 (rms 3.6 %), both operands
     of a product carry it, a K-long dot product of independent terms averages nothing away: each fp8 linear's output has ~5 % of
     relative noise.  The residual stream dilutes it (LayerScale 0.1-ish on the synthetic weights); measured on this model the
@@ -186,14 +187,14 @@ def test_vit_and_projector_fp8_mfma_against_bf16():
     eng.finalize()
     px = synthetic.make_pixels(5, seed=3).cuda()
     ref_last, ref_feat = eng.vit_forward(px), eng.extract_feature(px)
-    eng.enable_fp8_mfma(True)
+    eng.enable_fp8_mfma(True, level=level)      # 1: QKV, fc1, mlp1[1]; 2: fc2 as well (fed e4m3 rows by fc1's epilogue)
     last, feat = eng.vit_forward(px), eng.extract_feature(px)
     again = eng.extract_feature(px)
     eng.enable_fp8_mfma(False)
     back = eng.extract_feature(px)
     torch.cuda.synchronize()
     r1, r2 = rel_l2(last.float(), ref_last.float()), rel_l2(feat.float(), ref_feat.float())
-    print(f'fp8 MFMA ViT (2 layers) vs bf16: last hidden rel-L2 {r1:.3e}, projected features {r2:.3e}')
+    print(f'fp8 MFMA level {level} ViT (2 layers) vs bf16: last hidden rel-L2 {r1:.3e}, projected features {r2:.3e}')
     assert torch.isfinite(feat.float()).all()
     assert 0 < r1 <= 6e-2 and 0 < r2 <= 6e-2, (r1, r2)        # > 0: the option really changed the arithmetic
     assert torch.equal(feat, again)                            # deterministic
@@ -201,9 +202,10 @@ def test_vit_and_projector_fp8_mfma_against_bf16():
     eng.close()
 
 
-def test_llm_prefill_fp8_mfma_against_bf16():
-    """Two InternLM2 layers at full width: wqkv and w1|w3 of the prefill run e4m3 x e4m3 (4 of the 9 linears in front of the logits;
-    wo, w2 and the LM head stay bf16).  Noise budget on random-init weights (nothing averages out, see test_gpu_fp8.py): both
+@pytest.mark.parametrize('level', [1, 2])
+def test_llm_prefill_fp8_mfma_against_bf16(level):
+    """Two InternLM2 layers at full width: wqkv and w1|w3 of the prefill run e4m3 x e4m3 (level 1: 4 of the 9 linears in front of the
+    logits; level 2 adds wo and w2; the LM head stays bf16).  Noise budget on random-init weights (nothing averages out, see test_gpu_fp8.py): both
     operands of a product carry 3.6 % rms, so an fp8 linear's output carries ~5 %, the SwiGLU product of two such outputs ~7 %;
     two layers of (5 %, 7 %) entering the residual stream and passing the softmax: measured logits rel-L2 1.7e-1.  Bound 2.5e-1.
     The decode step after an fp8 prefill (bf16 kernels on the cache the fp8 prefill wrote, fed the bf16 run's token) stays inside
@@ -227,7 +229,7 @@ def test_llm_prefill_fp8_mfma_against_bf16():
     ref, _ = run()
     picks = ref.argmax(dim=1)
     ref, ref_step = run(picks)
-    eng.enable_fp8_mfma(True)
+    eng.enable_fp8_mfma(True, level=level)      # 1: wqkv and w1|w3; 2: wo and w2 as well (quantiser pass on their inputs)
     got, got_step = run(picks)
     got2, _ = run(picks)
     eng.enable_fp8_mfma(False)
@@ -235,7 +237,7 @@ def test_llm_prefill_fp8_mfma_against_bf16():
     torch.cuda.synchronize()
     r, rs = rel_l2(got, ref), rel_l2(got_step, ref_step)
     agree = int((got.argmax(dim=1) == picks).sum())
-    print(f'fp8 MFMA prefill (2 layers) vs bf16: logits rel-L2 {r:.3e}, next decode step {rs:.3e}, first picks equal {agree}/3')
+    print(f'fp8 MFMA level {level} prefill (2 layers) vs bf16: logits rel-L2 {r:.3e}, next decode step {rs:.3e}, first picks equal {agree}/3')
     assert 0 < r <= 2.5e-1 and 0 < rs <= 2.5e-1, (r, rs)
     assert torch.equal(got, got2)
     assert torch.equal(back, ref)

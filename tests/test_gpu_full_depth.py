@@ -372,36 +372,44 @@ def test_config1_example_page_end_to_end_vs_reference(gold, engine):
 
 
 def test_fp8_mfma_option_at_full_depth_is_recorded(gold, engine):
-    """The fp8 matrix-core option (OFF by default) at full depth against the same reference vectors: recorded next to the bf16
-    numbers in profiles/round3/full_depth_parity.json.  Random-init weights are the unfavourable case (every fp8 linear adds ~5 %
-    of independent relative noise and 24 / 32 layers of it accumulate); the assertions are sanity bounds, the gate on real weights
-    is evaluate.py --type full_page."""
+    """The fp8 matrix-core option (OFF by default) at full depth against the same reference vectors, both levels: recorded next to
+    the bf16 numbers in profiles/round3/full_depth_parity.json.  It is a THROUGHPUT option: e4m3 keeps 3 mantissa bits, every fp8 linear
+    adds ~5 % of independent relative noise and on random-init weights 24 / 32 layers of it accumulate, so the numbers below are far
+    outside the bf16 path's (and the greedy pick usually differs); what it costs on a real checkpoint is what
+    `evaluate.py --compare_fp8` measures.  The assertions are sanity bounds only, and level 1 (norm-fed linears only) must sit closer
+    to the reference than level 2."""
     g, meta = gold
     px = synthetic.make_pixels(2, seed=meta['pixels_seed'])
     S = meta['prompt_tokens']
     gen = torch.Generator().manual_seed(meta['prompt_seed'])
     emb = (torch.randn(1, S, 4096, generator=gen) * 0.02).to(torch.bfloat16)
     ref_logits = bits_to_f32(g['llm32.logits_bf16_bits'])[0]
-    engine.enable_fp8_mfma(True)
-    try:
-        feat = engine.extract_feature(px.cuda())
-        kv = engine.kv_alloc(1, 512)
-        lg = engine.prefill(kv, 0, emb.cuda(), want_logits=True).float().cpu().reshape(-1)
-        kv.free()
-    finally:
-        engine.enable_fp8_mfma(False)
-    torch.cuda.synchronize()
     ref = torch.from_numpy(g['vit24.feat.sample'])
-    got = subsample(feat.cpu(), int(g['vit24.feat.step']), ref.numel())
-    out = {'extract_feature_rel_l2_vs_reference': rel_l2(got, ref), 'prefill_logits_rel_l2_vs_reference': rel_l2(lg, ref_logits),
-           'prefill_pick_equal': bool(int(lg.argmax()) == int(ref_logits.argmax())),
-           'bf16_path_for_comparison': {'extract_feature': RESULTS.get('vit24', {}).get('feat', {}).get('rel_l2'),
-                                        'logits_worst': RESULTS.get('llm32', {}).get('worst_rel_l2')}}
+    out = {}
+    for level in (1, 2):
+        engine.enable_fp8_mfma(True, level=level)
+        try:
+            feat = engine.extract_feature(px.cuda())
+            kv = engine.kv_alloc(1, 512)
+            lg = engine.prefill(kv, 0, emb.cuda(), want_logits=True).float().cpu().reshape(-1)
+            kv.free()
+        finally:
+            engine.enable_fp8_mfma(False)
+        torch.cuda.synchronize()
+        got = subsample(feat.cpu(), int(g['vit24.feat.step']), ref.numel())
+        assert torch.isfinite(feat.float()).all() and torch.isfinite(lg).all()
+        out[f'level{level}'] = {'extract_feature_rel_l2_vs_reference': rel_l2(got, ref), 'prefill_logits_rel_l2_vs_reference': rel_l2(lg, ref_logits),
+                                'prefill_pick_equal': bool(int(lg.argmax()) == int(ref_logits.argmax()))}
+    out['bf16_path_for_comparison'] = {'extract_feature': RESULTS.get('vit24', {}).get('feat', {}).get('rel_l2'),
+                                       'logits_worst': RESULTS.get('llm32', {}).get('worst_rel_l2')}
+    out['reading'] = 'not parity-preserving on these weights at either level; a throughput option whose gate is evaluate.py --compare_fp8 on a real checkpoint'
     RESULTS['fp8_mfma_full_depth'] = out
     _dump()
     print('fp8 MFMA option at full depth:', json.dumps(out))
-    assert torch.isfinite(feat.float()).all() and torch.isfinite(lg).all()
-    assert out['extract_feature_rel_l2_vs_reference'] <= 0.2 and out['prefill_logits_rel_l2_vs_reference'] <= 0.8, out
+    for level in (1, 2):
+        o = out[f'level{level}']
+        assert o['extract_feature_rel_l2_vs_reference'] <= 0.2 and o['prefill_logits_rel_l2_vs_reference'] <= 0.8, out
+    assert out['level1']['prefill_logits_rel_l2_vs_reference'] <= out['level2']['prefill_logits_rel_l2_vs_reference'], out
 
 
 def test_vit_config2_properties(engine):

@@ -156,6 +156,25 @@ def _bit_exact_epilogues(E, g, M, N, K, kern):
     torch.testing.assert_close(out.float().cpu(), rb(torch.nn.functional.gelu(lin)), rtol=2 ** -7, atol=1e-6)
 
 
+def test_gelu_packed_pairs_equal_the_scalar_form(E):
+    """The 256x256 kernel evaluates GELU on pairs with packed fp32 instructions (common.hpp: gelu_erf2), the 128x128 kernel one
+    element at a time (gelu_erf): the same bits on every bf16 input, in both positions of a pair and beside any neighbour."""
+    bits = torch.arange(0, 65536, dtype=torch.int32)
+    x = (bits << 16).view(torch.float32)
+    x = x[torch.isfinite(x) & (x.abs() < 1e30) & ((x.abs() > 1e-30) | (x == 0))]
+    M, N, K = 2048 * ((x.numel() + 2047) // 2048), 512, 128
+    A = torch.zeros(M, K)
+    A[:x.numel(), 0] = x
+    A[:x.numel(), 1] = x.flip(0)                             # the pair partner: another input, of the other sign
+    W = torch.zeros(N, K)
+    W[0::2, 0] = 1.0                                         # even columns carry x, odd columns its partner
+    W[1::2, 1] = 1.0
+    a, w = bf(A).to(dev()), bf(W).to(dev())
+    o128, o256 = E.op_gemm(1, a, w, kernel=1), E.op_gemm(1, a, w, kernel=2)
+    torch.cuda.synchronize()
+    assert torch.equal(o128, o256)
+
+
 @pytest.mark.parametrize('kern', [1, 2])
 def test_gelu_epilogue_on_every_bf16_input(E, kern):
     """The GELU epilogue's input is always a bf16 value, so its whole domain is 65 k points: push every normal bf16

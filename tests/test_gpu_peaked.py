@@ -131,3 +131,28 @@ def test_free_running_logits_and_batched_decode(gold, model):
     _dump()
     print('peaked streams, logits and batch:', json.dumps(out))
     assert out['batched']['A_first_40_equal'] and out['batched']['B10_equal'], out['batched']
+
+
+def test_fp8_options_on_the_peaked_checkpoint_are_recorded(gold, model):
+    """The fp8 switches are throughput options, OFF by default; this records what they do to a stream whose reference margins are wide
+    (>= 2.6 at |logit| ~ 12): tokens of stream A equal to the reference's, first difference, per switch.  No equality is asserted -- the
+    record (profiles/round3/peaked_streams.json, key fp8) is the honest answer to "does fp8 keep the tokens on these weights"."""
+    g, meta = gold
+    ref_ids = g['A.ids'].tolist()
+    eng = model.engine
+    out = {}
+    for name, on, off in (('fp8_mfma_level1', lambda: eng.enable_fp8_mfma(True, level=1), lambda: eng.enable_fp8_mfma(False)),
+                          ('fp8_mfma_level2', lambda: eng.enable_fp8_mfma(True, level=2), lambda: eng.enable_fp8_mfma(False)),
+                          ('fp8_decode', lambda: eng.enable_fp8_decode(True), lambda: eng.enable_fp8_decode(False))):
+        on()
+        try:
+            got = _run(model, g['input_ids_a'], 1.0, len(ref_ids) + 8)
+        finally:
+            off()
+        first = next((i for i, (a, b) in enumerate(zip(got, ref_ids)) if a != b), None)
+        out[name] = {'tokens': len(got), 'equal_to_reference': got == ref_ids, 'first_difference': first,
+                     'tokens_equal_before_it': first if first is not None else min(len(got), len(ref_ids))}
+    assert _run(model, g['input_ids_a'], 1.0, 1024) == ref_ids          # switched off again: the bf16 stream is back
+    RESULTS['fp8'] = out
+    _dump()
+    print('peaked stream A under the fp8 options:', json.dumps(out))
