@@ -114,6 +114,39 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         }
     }
     int ks = W8 ? ksteps : 0;
+    if (WAVES == 1 && RT == 1 && !W8) {
+        // The tail kernel (launch_gemm_tail): ONE wave walks the whole K in ascending order (the tiled kernels' order: these rows must
+        // get their bits), so its time is a chain of load round trips -- 128 k-steps at K = 4096.  Two register batches of UR k-steps:
+        // the loads of batch b + 1 are in flight while batch b is multiplied (config 2's fc2 tail: 43 us per launch before).
+        bf16x8 wa[UR], wb[UR], xa[MT][UR], xb[MT][UR];
+        auto load = [&](bf16x8* w, bf16x8 (*x)[UR], int k0) {
+#pragma unroll
+            for (int u = 0; u < UR; u++) w[u] = __builtin_nontemporal_load((const bf16x8*)(wp[0] + (k0 + u) * 32));
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int u = 0; u < UR; u++) x[t][u] = *(const bf16x8*)(xp[t] + (k0 + u) * 32);
+        };
+        auto mma = [&](const bf16x8* w, const bf16x8 (*x)[UR]) {
+#pragma unroll
+            for (int u = 0; u < UR; u++)
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[t][u], acc[0][t], 0, 0, 0);
+        };
+        const int nb = ksteps / UR;
+        if (nb > 0) {
+            load(wa, xa, 0);
+            int b = 0;
+            for (; b + 2 <= nb; b += 2) {                    // (wa, xa) hold batch b
+                load(wb, xb, (b + 1) * UR);
+                mma(wa, xa);
+                if (b + 2 < nb) load(wa, xa, (b + 2) * UR);
+                mma(wb, xb);
+            }
+            if (b < nb) mma(wa, xa);
+            ks = nb * UR;
+        }
+    }
     for (; ks + UR <= ksteps; ks += UR) {
         bf16x8 w[RT][UR], x[MT][UR];
 #pragma unroll

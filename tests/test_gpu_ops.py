@@ -478,6 +478,32 @@ def test_attention_vit_shape(E):
     torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
 
 
+def test_attention_vit_shape_far_above_the_reference_point(E):
+    """attention_vit.hip keeps the reference point of its exponentials where the CLS key put it and never rescales inside the sweep; a
+    query whose scores lie far above that point (here +256: exp2 overflows, the row sum is not finite) must send its whole block
+    through the exact rescaling sweep.  Head 0 forces it for a few queries of several blocks, head 1 is ordinary data: both must match
+    the reference arithmetic, CLS query row included."""
+    g = torch.Generator().manual_seed(12)
+    Bn, S, H, D = 1, 1025, 2, 64
+    qkv = bf(_rand((Bn, S, 3 * H * D), g) * 0.5)
+    C3, C1 = 3 * H * D, H * D
+    spike = torch.full((D,), 4.0)
+    for qrow in (0, 5, 130, 131, 700, 1024):                 # the CLS query and patch queries of blocks 0, 1, 5, 7 (head 0)
+        qkv[0, qrow, 0:D] = spike                            # q . k = 0.125 * 4 * 4 * 64 = 128 against the spiked keys
+    qkv[0, 0, C1:C1 + D] = -spike                            # CLS key: score -128 for those queries = their reference point
+    for krow in (3, 400, 1000):
+        qkv[0, krow, C1:C1 + D] = spike                      # patch keys 256 above it
+    qkv = qkv.to(dev())
+    o = torch.zeros(Bn, S, C1, device=dev(), dtype=torch.bfloat16)
+    E.op_attention(qkv, qkv[:, :, C1:], qkv[:, :, 2 * C1:], o,
+                   [S * C3, C3, D, S * C3, C3, D, S * C3, C3, D, S * C1, C1, D], Bn, H, S, S, D, q_prescale=0.125)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    t = qkv.float().reshape(Bn, S, 3, H, D).permute(2, 0, 3, 1, 4)
+    ref = _attn_ref(t[0], t[1], t[2], False, 0, 0.125, 1.0).transpose(1, 2).reshape(Bn, S, C1)
+    torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
+
+
 def test_attention_exact_identity_layout(E):
     """V = one-hot rows, uniform scores: output row = mean of V rows -> exact in bf16; catches V^T/tr-read mistakes."""
     Bn, S, H, D = 1, 64, 1, 64
