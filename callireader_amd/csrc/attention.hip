@@ -378,18 +378,36 @@ int launch_t(const AttnParams& p, hipStream_t stream) {
 }
 
 // out[b][q][h][:] = sum_s exp(m_s - M) O_s / sum_s exp(m_s - M) l_s   (splits in index order: reproducible)
+// A wave's lane s fetches split s's (m, l) -- one round trip for up to 64 splits, maximum and weights by shuffles -- and the O rows are
+// loaded eight at a time with independent loads (a plain loop over the run-time split count waited for every load in turn: 13
+// dependent round trips per launch at 3 300 cached tokens, 11.5 us x 32 layers per decode step).
 template <int D>
 __global__ __launch_bounds__(D) void attn_combine_kernel(const AttnParams p) {
-    const int q = blockIdx.x, head = blockIdx.y, batch = blockIdx.z, d = threadIdx.x;
+    const int q = blockIdx.x, head = blockIdx.y, batch = blockIdx.z, d = threadIdx.x, lane = d & 63;
     const int64_t base = ((int64_t)batch * p.H + head) * p.nsplit;
     float M = -INFINITY;
-    for (int s = 0; s < p.nsplit; s++) M = fmaxf(M, p.part_ml[((base + s) * p.Sq + q) * 2]);
+    for (int s0 = 0; s0 < p.nsplit; s0 += 64) {
+        const int s = s0 + lane;
+        M = fmaxf(M, wave_max(s < p.nsplit ? p.part_ml[((base + s) * p.Sq + q) * 2] : -INFINITY));
+    }
     float L = 0.f, acc = 0.f;
-    for (int s = 0; s < p.nsplit; s++) {
-        const int64_t row = (base + s) * p.Sq + q;
-        const float w = __expf(p.part_ml[row * 2] - M);
-        L += w * p.part_ml[row * 2 + 1];
-        acc += w * p.part_o[row * D + d];
+    for (int s0 = 0; s0 < p.nsplit; s0 += 64) {
+        const int s = s0 + lane;
+        const bool in = s < p.nsplit;
+        const int64_t row = (base + (in ? s : 0)) * p.Sq + q;
+        const float w = in ? __expf(p.part_ml[row * 2] - M) : 0.f;
+        const float wl = in ? w * p.part_ml[row * 2 + 1] : 0.f;
+        const int n = min(64, p.nsplit - s0);
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = j0 + j < n ? p.part_o[((base + s0 + j0 + j) * p.Sq + q) * D + d] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {                    // index order; lanes past the count carry weight 0
+                L += __shfl(wl, j0 + j, 64);
+                acc += __shfl(w, j0 + j, 64) * o[j];
+            }
+        }
     }
     p.O[(int64_t)batch * p.o_bs + (int64_t)q * p.o_rs + (int64_t)head * p.o_hs + d] = f2bf(acc / L);
 }

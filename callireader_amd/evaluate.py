@@ -18,8 +18,14 @@
                                                           and full_page_<level>_fp8_vs_bf16.json holds the per-page agreement and the F1 / NED deltas
   (new) one process per GPU under torchrun                 every rank takes a contiguous share of each file's pages, rows gathered on rank 0
 
-The other CalliBench tasks (region_wise, choice, bilingual, intent) score different abilities with external judges and are
-outside SURVEY.md section 8.  `batch_pages` > 1 sends that many pages through the engine together, two batches in flight
+  evaluate.py:173-213 test_region_wise                    test_region_wise (crop `region`, score against `answer`)
+  evaluate.py:78-123  evaluate_accuracy                   evaluate_accuracy (pinned to the reference's function: tests/golden/eval_vectors.json)
+  evaluate.py:216-313 test_choice                         test_choice (two turns: transcription, then the multiple-choice question with
+                                                          the first turn as history; the reference scores the first 3 samples only, :257,301
+                                                          -- `limit=3` by default here, `--choice_limit 0` lifts it)
+  evaluate.py:317-386 test_bilingual / test_intent        the same two turns, answers stored for the reference's external judges (eval/: an STS
+                                                          model and an LLM API, not part of this package)
+`batch_pages` > 1 sends that many pages through the engine together, two batches in flight
 (InternVLChatModel.chat_ocr_stream): each page's response equals its own chat_ocr call, pages/s is what changes.
 """
 import argparse
@@ -167,6 +173,128 @@ def test_full_page(parquet_path, save_json_path, model, tokenizer, detect_model,
     return to_be_save['average']
 
 
+def _crop_region(img, region):
+    import numpy as np
+    (x1, y1), (x2, y2) = region
+    return Image.fromarray(np.array(img.convert('RGB'))[y1:y2, x1:x2])
+
+
+def test_region_wise(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, prompt, use_p, hard_vq, drop_zero,
+                     repetition_penalty, verbose, limit=None):
+    """evaluate.py:173-213: every row names a `region` [[x1, y1], [x2, y2]] of its page; the crop goes through chat_ocr like a page and
+    is scored against `answer` with the full-page metrics."""
+    images, annotations = get_parquet(parquet_path)
+    if limit:
+        images, annotations = images[:limit], annotations[:limit]
+    rows, sums = [], [0.0, 0.0, 0.0, 0.0]
+    for img, annot in zip(images, annotations):
+        response = single_rec(model, tokenizer, detect_model, generation_config, _crop_region(img, annot['region']), prompt, use_p, hard_vq, drop_zero,
+                              repetition_penalty, verbose)
+        response, gt, precision, recall, f1, ned = score_page(response, annot['answer'])
+        rows.append({'imgPath': annot['imagePath'], 'prompt': prompt, 'output': ''.join(response), 'gt': ''.join(gt),
+                     'precision': precision, 'recall': recall, 'f1': f1, 'ned': ned})
+        for k, v in enumerate((precision, recall, f1, ned)):
+            sums[k] += v
+    n = max(len(rows), 1)
+    report = {'detailed': rows, 'average': {'ave_precison': sums[0] / n, 'avg_recall': sums[1] / n, 'avg_f1': sums[2] / n, 'avg_ned': sums[3] / n}, 't2s': cc.name}
+    with open(save_json_path, 'w', encoding='utf-8') as f:
+        json.dump(report, f, ensure_ascii=False, indent=4)
+    return report['average']
+
+
+def evaluate_accuracy(responses, correct_answers):
+    """evaluate.py:78-123.  correct_answers[i] = (letter, its text, the two other options' texts).  A response counts when it names
+    exactly the right letter among A / B / C -- unless it quotes an option's TEXT: quoting the right text and neither wrong one
+    counts whatever the letters say, quoting the right text and a wrong one does not."""
+    assert len(responses) == len(correct_answers), 'Responses and answers must have the same length.'
+    right = 0
+    for response, (letter, text_gt, wrong0, wrong1) in zip(responses, correct_answers):
+        named = [c for c in 'ABC' if c in response]
+        ok = len(named) <= 1 and (named[0] if named else None) == letter
+        if text_gt in response:
+            ok = not (wrong0 in response or wrong1 in response)
+        right += bool(ok)
+    return right / len(responses) * 100
+
+
+def parse_choice(prompt, letter):
+    """evaluate.py:235-257: the option lines of a multiple-choice prompt ("A: ...", "B: ...", "C: ..."): returns
+    (letter, the right option's text, the two other options' texts in prompt order)."""
+    right, wrong = None, []
+    for line in prompt.split('\n'):
+        if not any(c in line for c in 'ABC'):
+            continue
+        if line.startswith(letter + ':'):
+            right = line
+        elif len(wrong) < 2:
+            wrong.append(line)
+    return (letter, right.split(':')[1].strip(), wrong[0].split(':')[1].strip(), wrong[1].split(':')[1].strip())
+
+
+FIRST_TURN = '这幅书法作品内容是什么？'
+
+
+def _two_turns(model, tokenizer, detect_model, generation_config, img, second_question, use_p, hard_vq, drop_zero, repetition_penalty, verbose):
+    """The reference's reasoning tasks ask for the transcription first and put the actual question as a second turn on that history."""
+    kw = dict(use_p=use_p, hard_vq=hard_vq, drop_zero=drop_zero, repetition_penalty=repetition_penalty, return_history=True, verbose=verbose)
+    _, history = model.chat_ocr(tokenizer, detect_model, img, FIRST_TURN, generation_config, **kw)
+    response, history = model.chat_ocr(tokenizer, detect_model, img, second_question, generation_config, history=history, **kw)
+    return response
+
+
+def test_choice(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, use_p=True, hard_vq=False, drop_zero=True,
+                repetition_penalty=1.0, verbose=False, limit=3):
+    """evaluate.py:216-313 (author / style / layout).  The reference scores the first three samples of each file (:257, :301); limit=0
+    scores all."""
+    images, annotations = get_parquet(parquet_path)
+    answers = [parse_choice(a['conversations'][0]['value'], a['conversations'][1]['value']) for a in annotations]
+    if limit:
+        images, annotations, answers = images[:limit], annotations[:limit], answers[:limit]
+    responses, rows = [], []
+    for img, annot, gt in zip(images, annotations, answers):
+        prompt = annot['conversations'][0]['value'].replace('<image>\n', '')
+        response = _two_turns(model, tokenizer, detect_model, generation_config, img, prompt + '\n只需要输出问题的答案，禁止输出其他内容！答案：',
+                              use_p, hard_vq, drop_zero, repetition_penalty, verbose)
+        responses.append(response)
+        rows.append({'imgPath': annot['image'], 'output': response, 'reference': gt[0]})
+    accuracy = evaluate_accuracy(responses, answers) if responses else 0.0
+    report = {'detailed': rows, 'summary': {'total_samples': len(responses), 'accuracy': accuracy}}
+    with open(save_json_path, 'w', encoding='utf-8') as f:
+        json.dump(report, f, ensure_ascii=False, indent=4)
+    return accuracy, report
+
+
+def _test_reasoning(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, use_p, hard_vq, drop_zero, repetition_penalty,
+                    verbose, with_content, limit=None):
+    """evaluate.py:317-386: question = the prompt up to its first option line; the answer is split at "INTENT:" and stored for the
+    external judges of eval/ (not run here)."""
+    images, annotations = get_parquet(parquet_path)
+    if limit:
+        images, annotations = images[:limit], annotations[:limit]
+    rows = []
+    for img, annot in zip(images, annotations):
+        prompt = annot['conversations'][0]['value']
+        m = re.search(r'^(.*?)\n[A-Z]:', prompt, re.DOTALL)
+        question = m.group(1).strip() if m else prompt
+        response = _two_turns(model, tokenizer, detect_model, generation_config, img, question, use_p, hard_vq, drop_zero, repetition_penalty, verbose)
+        row = {'imgPath': annot['image'], 'chinese': response.split('INTENT:')[0], 'answer': response.split('INTENT:')[-1],
+               'gt': annot['conversations'][-1]['value']}
+        if with_content:
+            row['calligraphy_content'] = annot['content']
+        rows.append(row)
+    with open(save_json_path, 'w', encoding='utf-8') as f:
+        json.dump({'detailed': rows}, f, ensure_ascii=False, indent=4)
+    return rows
+
+
+def test_bilingual(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, use_p, hard_vq, drop_zero, repetition_penalty, verbose, limit=None):
+    return _test_reasoning(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, use_p, hard_vq, drop_zero, repetition_penalty, verbose, False, limit)
+
+
+def test_intent(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, use_p, hard_vq, drop_zero, repetition_penalty, verbose, limit=None):
+    return _test_reasoning(parquet_path, save_json_path, model, tokenizer, detect_model, generation_config, use_p, hard_vq, drop_zero, repetition_penalty, verbose, True, limit)
+
+
 def compare_reports(bf16_rows, fp8_rows):
     """--compare_fp8: the same pages through the bf16 path and through the fp8 switches -> what changed.  Rows are the `detailed`
     entries test_full_page writes (same order).  The gate BASELINE config 5 needs is delta_f1 / delta_ned on real weights."""
@@ -190,7 +318,9 @@ def compare_reports(bf16_rows, fp8_rows):
 
 def main(argv=None):
     parser = argparse.ArgumentParser(description='args for inference task')
-    parser.add_argument('--type', type=str, choices=['full_page'], default='full_page', help='Evaluation Type (this engine covers full_page)')
+    parser.add_argument('--type', type=str, choices=['full_page', 'region_wise', 'choice', 'bilingual', 'intent'], default='full_page',
+                        help='Evaluation Type (full_page, region_wise, choice, bilingual, intent)')
+    parser.add_argument('--choice_limit', type=int, default=3, help='samples scored per choice file (the reference scores 3; 0 = all)')
     parser.add_argument('--save_name', type=str, default='exp')
     parser.add_argument('--data', type=str, default='./CalliBench', help='Evaluation Data Directory')
     parser.add_argument('--use_p', type=bool, default=True)
@@ -244,6 +374,29 @@ def main(argv=None):
     tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
     generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
     detect_model = load_detector(args.params)
+    common = (args.use_p, args.hard_vq, args.drop_zero, args.repetition_penalty, args.verbose)
+    if args.type != 'full_page':
+        # the other CalliBench tasks are page-at-a-time host loops over chat_ocr (rank 0 only; evaluate.py:438-466)
+        if rank == 0:
+            if args.type == 'region_wise':
+                print(test_region_wise(os.path.join(args.data, 'region-wise/region.parquet'), os.path.join(save_dir, 'region_wise.json'), model, tokenizer,
+                                       detect_model, generation_config, '读出图中区域所有文字。', *common))
+            elif args.type == 'choice':
+                for name in ('author', 'style', 'layout'):
+                    acc, _ = test_choice(os.path.join(args.data, f'choice/{name}/{name}.parquet'), os.path.join(save_dir, f'{name}.json'), model, tokenizer,
+                                         detect_model, generation_config, *common, limit=args.choice_limit)
+                    print(name, acc)
+            elif args.type == 'bilingual':
+                test_bilingual(os.path.join(args.data, 'reasoning/bilingual/medium/bilingual_medium.parquet'), os.path.join(save_dir, 'bilingual.json'), model,
+                               tokenizer, detect_model, generation_config, *common)
+            else:
+                test_intent(os.path.join(args.data, 'reasoning/intent/intent.parquet'), os.path.join(save_dir, 'intent.json'), model, tokenizer, detect_model,
+                            generation_config, *common)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     prompt = '读出图中所有文字。'
     for level in ('easy', 'medium', 'hard'):
         parquet_path = os.path.join(args.data, f'full_page_ocr/{level}/{level}.parquet')

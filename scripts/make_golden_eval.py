@@ -43,7 +43,19 @@ metrics = []
 for p, g in pairs:
     pr, rc, f1 = calculate_metrics(list(p), list(g))
     metrics.append({'pred': p, 'gt': g, 'precision': pr, 'recall': rc, 'f1': f1, 'edit_distance_textbook': textbook_edit_distance(list(p), list(g))})
+# evaluate_accuracy (evaluate.py:78-123) on one response at a time: letters named, option texts quoted, both, neither
+answers = [('A', '王羲之', '颜真卿', '柳公权'), ('B', '楷书', '行书', '草书'), ('C', '竖排', '横排', '扇面')]
+frags = ['A', 'B', 'C', 'A。', '答案：B', '选C', 'A和B', 'ABC', '', '王羲之', '颜真卿', '楷书', '行书', '竖排', 'A 王羲之', 'B 王羲之', '王羲之或颜真卿', 'C：竖排', 'B：行书', '不知道',
+         'A: 颜真卿', '楷书，不是草书', 'C 扇面', '答案是 B：楷书']
+choice = []
+for ans in answers:
+    for r in frags:
+        choice.append({'response': r, 'answer': list(ans), 'accuracy': ref_eval.evaluate_accuracy([r], [ans])})
+for _ in range(30):
+    ans = rng.choice(answers)
+    r = ''.join(rng.choice(frags + ['，', ' ']) for _ in range(rng.randint(1, 3)))
+    choice.append({'response': r, 'answer': list(ans), 'accuracy': ref_eval.evaluate_accuracy([r], [ans])})
 clean = ['君不见，黄河之水天上来！', 'Hello, world. (123) [x]-{y}*\n“引号”《书名》：；…—', '无标点', '', '1234567890', "it's; a: \"test\"?"]
-out = {'_how': 'scripts/make_golden_eval.py', 'metrics': metrics, 'clean': [{'in': c, 'out': ref_eval.get_clean_string(c)} for c in clean]}
+out = {'_how': 'scripts/make_golden_eval.py', 'metrics': metrics, 'choice': choice, 'clean': [{'in': c, 'out': ref_eval.get_clean_string(c)} for c in clean]}
 json.dump(out, open(os.path.join(ROOT, 'tests', 'golden', 'eval_vectors.json'), 'w'), ensure_ascii=False, indent=1)
 print('ok', len(metrics), 'metric cases')

@@ -31,7 +31,7 @@ class FakeTokenizer:
         return [' '.join(('<|im_end|>' if int(t) == 8992 else str(int(t))) for t in row) for row in out]
 
 
-def oracle_chat_ocr(sd, dims, img, boxes, tok, question, max_new, penalty, use_p=True, drop_zero=False):
+def oracle_chat_ocr(sd, dims, img, boxes, tok, question, max_new, penalty, use_p=True, drop_zero=False, history=None):
     from oracle import vision, calli_align, generate
     with torch.no_grad():
         page_px = preprocess.load_image(img).to(torch.bfloat16)
@@ -44,8 +44,11 @@ def oracle_chat_ocr(sd, dims, img, boxes, tok, question, max_new, penalty, use_p
             rs = calli_align.resampler_forward(sd, feats, dims.rs_depth)
             idx = calli_align.vq_cos_sim(sd['normed_emb.weight'], rs)
             out_tokens, _ = calli_align.denormalise(rs, idx.reshape(rs.shape[0], 3), sd['normed_emb.weight'], sd['calli.mu'], sd['calli.sigma'], drop_zero=drop_zero)
-            q = q + '[UNUSED_TOKEN_140]' * out_tokens.shape[0]
+            if history is None:                                   # a later turn carries the pseudo-token ids in its history only (:698-699)
+                q = q + '[UNUSED_TOKEN_140]' * out_tokens.shape[0]
         t = get_conv_template('internlm2-chat')
+        for old_q, old_a in (history or []):                      # :711-713
+            t.append_message(t.roles[0], old_q); t.append_message(t.roles[1], old_a)
         t.append_message(t.roles[0], q); t.append_message(t.roles[1], None)
         query = t.get_prompt().replace('<image>', '<img>' + '<IMG_CONTEXT>' * 256 * page_px.shape[0] + '</img>', 1)
         ids = tok(query)['input_ids']

@@ -121,3 +121,64 @@ def test_main_refuses_to_score_without_t2s(monkeypatch):
         pytest.skip('opencc is installed here')
     with pytest.raises(SystemExit, match='opencc'):
         ev.main(['--data', '/nonexistent'])
+
+
+def test_choice_scoring_equals_the_reference():
+    for c in GOLD['choice']:
+        assert ev.evaluate_accuracy([c['response']], [tuple(c['answer'])]) == c['accuracy'], c
+    rs, ans = [c['response'] for c in GOLD['choice']], [tuple(c['answer']) for c in GOLD['choice']]
+    assert abs(ev.evaluate_accuracy(rs, ans) - sum(c['accuracy'] for c in GOLD['choice']) / len(rs)) < 1e-9
+
+
+class TwoTurnModel:
+    """chat_ocr stand-in that answers the transcription turn and then the task turn (history must be the first turn's)."""
+    def __init__(self, answers):
+        self.answers, self.calls = list(answers), []
+
+    def chat_ocr(self, tokenizer, detect_model, image, prompt, generation_config, history=None, return_history=True, **kw):
+        self.calls.append((image.size, prompt, history))
+        if history is None:
+            return '春眠不觉晓', [(prompt, '春眠不觉晓')]
+        assert history == [(ev.FIRST_TURN, '春眠不觉晓')]
+        return self.answers.pop(0), history + [(prompt, 'x')]
+
+
+def make_task_parquet(path, rows):
+    pd = pytest.importorskip('pandas')
+    out = []
+    for i, annot in enumerate(rows):
+        buf = io.BytesIO()
+        Image.new('RGB', (50 + i, 40), (255, 255, 255)).save(buf, format='PNG')
+        out.append({'annotation': json.dumps(annot, ensure_ascii=False), 'image': {'bytes': buf.getvalue()}})
+    pd.DataFrame(out).to_parquet(path)
+
+
+def test_choice_and_reasoning_runs(tmp_path):
+    q = '<image>\n这幅作品的作者是谁？\nA: 颜真卿\nB: 王羲之\nC: 柳公权'
+    rows = [{'image': f'c{i}.jpg', 'conversations': [{'value': q}, {'value': 'B'}], 'content': '春眠不觉晓'} for i in range(4)]
+    pq = str(tmp_path / 'author.parquet')
+    make_task_parquet(pq, rows)
+    assert ev.parse_choice(q, 'B') == ('B', '王羲之', '颜真卿', '柳公权')
+    m = TwoTurnModel(['B', '颜真卿', 'A 王羲之', 'B'])
+    acc, rep = ev.test_choice(pq, str(tmp_path / 'author.json'), m, None, None, {})          # the reference scores the first three samples
+    assert rep['summary']['total_samples'] == 3 and abs(acc - 200 / 3) < 1e-9
+    assert m.calls[1][1] == q.replace('<image>\n', '') + '\n只需要输出问题的答案，禁止输出其他内容！答案：'
+    m = TwoTurnModel(['B', 'B', 'B', 'C'])
+    acc, rep = ev.test_choice(pq, str(tmp_path / 'author_all.json'), m, None, None, {}, limit=0)
+    assert rep['summary']['total_samples'] == 4 and acc == 75.0
+    m = TwoTurnModel(['春眠 INTENT: 咏春'] * 4)
+    out = ev.test_intent(pq, str(tmp_path / 'intent.json'), m, None, None, {}, True, False, False, 1.0, False)
+    assert out[0] == {'imgPath': 'c0.jpg', 'chinese': '春眠 ', 'answer': ' 咏春', 'gt': 'B', 'calligraphy_content': '春眠不觉晓'}
+    assert m.calls[1][1] == '<image>\n这幅作品的作者是谁？'                                   # the prompt up to its first option line
+    assert 'calligraphy_content' not in ev.test_bilingual(pq, str(tmp_path / 'bi.json'), TwoTurnModel(['x'] * 4), None, None, {}, True, False, False, 1.0, False)[0]
+
+
+def test_region_wise_run(tmp_path):
+    rows = [{'imagePath': 'r0.jpg', 'region': [[5, 4], [30, 20]], 'answer': '高堂，明镜'}, {'imagePath': 'r1.jpg', 'region': [[0, 0], [10, 10]], 'answer': '白发'}]
+    pq = str(tmp_path / 'region.parquet')
+    make_task_parquet(pq, rows)
+    m = FakeModel(['高堂明镜', '白头'])
+    avg = ev.test_region_wise(pq, str(tmp_path / 'region.json'), m, None, None, {}, '读出图中区域所有文字。', True, False, False, 1.0, False)
+    rep = json.load(open(str(tmp_path / 'region.json'), encoding='utf-8'))
+    assert m.calls[0][0] == (25, 16) and m.calls[1][0] == (10, 10)                           # the crops, not the pages
+    assert rep['detailed'][0]['f1'] == 1.0 and rep['detailed'][1]['gt'] == '白发' and abs(avg['avg_f1'] - rep['average']['avg_f1']) < 1e-12

@@ -50,6 +50,21 @@ def test_chat_ocr_matches_oracle_pipeline(setup):
     assert isinstance(r2, str) and r2 == tok.batch_decode(ref_ids2)[0].split('<|im_end|>')[0].strip()
 
 
+def test_chat_ocr_second_turn_on_the_first_turns_history(setup):
+    """The reference's choice / bilingual / intent tasks (evaluate.py:259-287, 324-342) ask for the transcription and then put the real
+    question as a second turn with the first turn as history: the second prompt holds the pseudo-token ids inside the history's question
+    only, its own '<image>' stays literal text (only the first one is expanded, :716-719), and the same pseudo tokens are spliced again."""
+    m, tok = setup['model'], setup['tok']
+    gen = dict(num_beams=1, max_new_tokens=5, do_sample=False)
+    r1, hist = m.chat_ocr(tok, None, setup['img'], 'what?', gen, use_p=True, repetition_penalty=1.0, return_history=True, boxes=setup['boxes'])
+    first = list(hist)
+    ref_ids, ref_q, _ = oracle_chat_ocr(setup['sd'], setup['dims'], setup['img'], setup['boxes'], tok, 'who wrote it?', 5, 1.0, history=first)
+    r2, hist2 = m.chat_ocr(tok, None, setup['img'], 'who wrote it?', gen, use_p=True, repetition_penalty=1.0, return_history=True,
+                           boxes=setup['boxes'], history=hist)
+    assert r2 == tok.batch_decode(ref_ids)[0].split('<|im_end|>')[0].strip()
+    assert hist2 == first + [(ref_q, r2)] and ref_q == '<image>\nwho wrote it?'
+
+
 def test_chat_plain_and_errors(setup):
     m, tok = setup['model'], setup['tok']
     px = preprocess.load_image(setup['img']).to(torch.bfloat16)
