@@ -111,13 +111,27 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
     };
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto stage = [&](int buf, int kt) {
+    // scalar source bases of this wave's two pieces, kept as running pointers: a tile step is one 64-bit scalar add per piece (the
+    // 64-bit row * stride products of a per-tile recomputation were ~50 scalar instructions a tile)
+    const int64_t k_step = 64 * p.k_rs, v_step = 64 * p.v_rs;               // elements per key tile
+    const bf16* ksrc[IPW];
+    const bf16* vsrc[IPW];
+    auto seek = [&](int kt) {
 #pragma unroll
         for (int ii = 0; ii < IPW; ii++) {
-            const int64_t row = (int64_t)kt * 64 + (wave * IPW + ii) * RPI;                 // scalar
+            const int64_t row = (int64_t)kt * 64 + (wave * IPW + ii) * RPI;
+            ksrc[ii] = Kb + row * p.k_rs;
+            vsrc[ii] = Vb + row * p.v_rs;
+        }
+    };
+    auto stage = [&](int buf) {                              // the tile ksrc / vsrc point at, then on to the next one
+#pragma unroll
+        for (int ii = 0; ii < IPW; ii++) {
             const unsigned dst = smem_base + buf * (2 * TILE) + (wave * IPW + ii) * 1024;
-            dma16(Kb + row * p.k_rs, k_voff[ii], dst);
-            dma16(Vb + row * p.v_rs, v_voff, dst + TILE);
+            dma16(ksrc[ii], k_voff[ii], dst);
+            dma16(vsrc[ii], v_voff, dst + TILE);
+            ksrc[ii] += k_step;
+            vsrc[ii] += v_step;
         }
     };
     f32x16 oacc[DB];
@@ -220,7 +234,8 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
     auto sweep = [&](auto exact) {
         int kt = 2 * qb + 2;
         if (kt >= NT) kt -= NT;
-        stage(0, kt);
+        seek(kt);
+        stage(0);
         init_state();
         const float m2f = m_run * LOG2E;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -228,8 +243,8 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
         for (int i = 0; i < NT; i++) {
             const int cur = i & 1;
             if (i + 1 < NT) {
-                kt = kt + 1 == NT ? 0 : kt + 1;
-                stage(cur ^ 1, kt);
+                if (++kt == NT) { kt = 0; seek(0); }         // the rotated sweep wraps once
+                stage(cur ^ 1);
             }
             const char* kbuf = smem + cur * (2 * TILE);
             const char* vbuf = kbuf + TILE;
