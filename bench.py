@@ -138,7 +138,7 @@ def measure_traffic(pages=16):
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(work, counter)
             r = subprocess.run([prof, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + args,
-                               cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+                               cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f'rocprofv3 --pmc {counter} failed (rc {r.returncode}): ' + r.stdout.decode(errors='replace')[-300:]
