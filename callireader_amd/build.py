@@ -16,7 +16,9 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'callir
 
 # attention.hip: scores never hold a NaN (masked keys are -inf, and an all-masked row is never exponentiated), and
 # without the assumption every fmaxf on an accumulator costs an extra canonicalising v_max_f32
-EXTRA_FLAGS = {'attention.hip': ['-fno-honor-nans'], 'attention_vit.hip': ['-fno-honor-nans']}
+# attention_vit.hip, -fno-slp-vectorize: the SLP pass packs the row-sum adds into v_pk_add_f32, which issue slower beside MFMAs than the
+# plain adds they replace (guide: 'packed f32 VALU ... an anti-lever beside MFMAs'): 1.453 -> 1.432 ms per 255-tile launch, same bits
+EXTRA_FLAGS = {'attention.hip': ['-fno-honor-nans'], 'attention_vit.hip': ['-fno-honor-nans', '-fno-slp-vectorize']}
 
 
 def sources():

@@ -42,25 +42,15 @@ constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB, KS = 4, DB = 2, CPR = 8, RPI
 __device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
-__global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
+// One 128-query block of one (tile, head).  EXACT = false: the lean sweep, the block's verdict on it (flag), the output, the block's
+// share of the CLS query.  EXACT = true: the same block again in the exact rescaling form (vit_attn_exact_kernel, flagged blocks only).
+template <bool EXACT>
+__device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb, const int head, const int batch, const int gx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    // XCD-aware order (attention.hip): the query blocks of one (tile, head) read their K/V through ONE L2
-    int qb, head, batch;
-    const int gx = gridDim.x;
-    {
-        const int gy = gridDim.y;
-        const int total = gx * gy * (int)gridDim.z;
-        const int lin = blockIdx.x + gx * (blockIdx.y + gy * (int)blockIdx.z);
-        const int xcd = lin & 7, q = total >> 3, r = total & 7;
-        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-        qb = pid % gx;
-        head = (pid / gx) % gy;
-        batch = pid / (gx * gy);
-    }
     const int NT = 2 * gx;                                  // 64-key tiles of patch keys
     const bf16* Qb = p.Q + (int64_t)batch * p.q_bs + (int64_t)head * p.q_hs;
     const bf16* Kc = p.K + (int64_t)batch * p.k_bs + (int64_t)head * p.k_hs;         // row 0 = the CLS key
@@ -264,10 +254,18 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
             __builtin_amdgcn_s_barrier();
         }
     };
-    sweep(std::false_type{});
-    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    // (NaN compares false: a non-finite sum takes the exact sweep as well; the vote is workgroup-uniform, the sweeps share barriers)
-    if (__syncthreads_or(!(l_tot < 1.2676506002282294e30f))) {
+    // The lean sweep's verdict (NaN compares false: a non-finite row sum is flagged as well) goes to the block's flag word; flagged
+    // blocks are redone by vit_attn_exact_kernel.  (With the exact sweep inside this kernel -- a workgroup-uniform branch behind the
+    // vote -- the kernel took 168 registers for code that all but never runs: 3 waves per SIMD; alone the lean form fits 128 and
+    // four: 1.478 -> 1.412 ms per 255-tile launch in one process.)
+    int* const flags = (int*)(p.part_o + (size_t)p.B * p.H * (4 * gx + 1) * D);
+    float l_tot;
+    if constexpr (!EXACT) {
+        sweep(std::false_type{});
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const int bad = __syncthreads_or(!(l_tot < 1.2676506002282294e30f));
+        if (tid == 0) flags[((int64_t)batch * p.H + head) * gx + qb] = bad;
+    } else {
         sweep(std::true_type{});
         l_tot = l_run + __shfl_xor(l_run, 32, 64);
     }
@@ -287,6 +285,7 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
             }
     }
 
+    if constexpr (EXACT) return;
     // ---- the CLS query: this wave's 32 keys of the block's last two tiles (still in LDS: tile 2qb in buffer 0, 2qb + 1 in buffer 1)
     load_q(0, qf);                                          // every lane column holds the same query
     const int nsplit = 4 * gx + 1;
@@ -345,6 +344,30 @@ __global__ __launch_bounds__(256, 3) void vit_attn_kernel(const AttnParams p) {
     }
 }
 
+__global__ __launch_bounds__(256, 4) void vit_attn_kernel(const AttnParams p) {
+    // XCD-aware order (attention.hip): the query blocks of one (tile, head) read their K/V through ONE L2
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * (int)gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * (int)blockIdx.z);
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    vit_attn_body<false>(p, pid % gx, (pid / gx) % gy, pid / (gx * gy), gx);
+}
+
+// One workgroup per tile: redo the (head, query block)s the lean sweep flagged (a score ~88 above the CLS key's: none on real pages).
+// The tile's H * nb flag words are fetched in ONE round trip (a loop of dependent one-word loads per (tile, head) cost 47 us per
+// 255-tile launch with nothing flagged).
+__global__ __launch_bounds__(256) void vit_attn_exact_kernel(const AttnParams p, const int nb) {
+    const int batch = blockIdx.x, n = p.H * nb;
+    const int* flags = (const int*)(p.part_o + (size_t)p.B * p.H * (4 * nb + 1) * D) + (int64_t)batch * n;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + (int)threadIdx.x;
+        if (!__syncthreads_or(j < n ? flags[j] : 0)) continue;
+        for (int jj = j0; jj < n && jj < j0 + 256; jj++)
+            if (__builtin_amdgcn_readfirstlane(flags[jj])) vit_attn_body<true>(p, jj % nb, jj / nb, batch, nb);
+    }
+}
+
 // O[cls][d] = sum_s exp(m_s - M) O_s[d] / sum_s exp(m_s - M) l_s over the (tile, head)'s partials, in index order (reproducible).
 // One wave per (tile, head): lane s fetches partial s's (m, l) -- ONE round trip for all of them, the maximum and the weights by
 // shuffles -- then lane d sums the weighted O rows with every load of the loop independent (a plain loop over a run-time count
@@ -396,16 +419,18 @@ bool vit_attn_supported(const AttnParams& p, int head_dim, bool causal) {
            (p.o_rs & 3) == 0 && (p.q_hs & 7) == 0 && (p.k_hs & 7) == 0 && (p.v_hs & 3) == 0 && (p.o_hs & 3) == 0;
 }
 
-size_t vit_attn_ws_floats(int B, int H, int S) { return (size_t)B * H * (4 * ((S - 1) / 128) + 1) * (64 + 2); }
+// per (tile, head): 4 nb + 1 partials of [m, l] and O[64], then nb flag words
+size_t vit_attn_ws_floats(int B, int H, int S) { const int nb = (S - 1) / 128; return (size_t)B * H * ((4 * nb + 1) * (64 + 2) + nb); }
 
 int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * TILE;
-    static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS)) return CR_ERR_HIP;
+    static std::atomic<uint64_t> attr_done{0}, attr_done_x{0};
+    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS) || !cr_dyn_lds_once(attr_done_x, (const void*)vit_attn_exact_kernel, LDS)) return CR_ERR_HIP;
     const int nb = (p.Sq - 1) / 128;
     AttnParams q = p;
     q.part_o = p.part_ml + (size_t)p.B * p.H * (4 * nb + 1) * 2;       // one allocation: [m, l] pairs, then the O partials
     hipLaunchKernelGGL(vit_attn_kernel, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
+    hipLaunchKernelGGL(vit_attn_exact_kernel, dim3(p.B), dim3(256), LDS, stream, q, nb);
     if (nb == 8) hipLaunchKernelGGL(vit_cls_combine_kernel<33>, dim3(p.H, p.B), dim3(64), 0, stream, q);
     else hipLaunchKernelGGL(vit_cls_combine_any_kernel, dim3(p.H, p.B), dim3(64), 0, stream, q, 4 * nb + 1);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;

@@ -88,10 +88,64 @@ constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per 
 //   slice image: row r at r*128 B; the 8-byte slot s of a row sits at (s ^ r): the 16 lanes of a ds_write_b64 group
 //   (rows 0..15, same s) hit 16 different bank pairs, and the 16-byte read-back chunk c = (slot pair) is found at
 //   c ^ (r >> 1) with its halves exchanged when r is odd.
+// ---- GELU by table (EPI_GELU) ----------------------------------------------------------------------------------------
+// The input of the GELU is a bf16 value (the rounded linear output), its result is rounded to bf16: a function of 16 bits.  Every
+// workgroup fills a table of it in LDS at its start (gelu_erf on each entry: the table IS the formula, bit for bit) for the inputs
+// 2^-17 <= |x| < 2^5 (22 exponents x 128 mantissas per sign, 11 KiB), and the epilogue turns ~17 packed fp32 operations + rcp + exp2
+// per pair of elements (the vector pipe's whole throughput for 12 k of fc1's 19 k epilogue clocks) into ~9 integer
+// operations and two 2-byte LDS gathers.  A slice that holds a value outside the window (zero, denormal-small, |x| >= 32, inf, NaN:
+// a wave-uniform vote on the packed maximum of the slice's magnitudes) is redone with the formula.
+// Layout of the wave-private 32 KiB behind the K buffers for this instance: positive table at 0, negative table at 8192 (the sign
+// bit lands on address bit 13), ONE 2 KiB staging slice per wave in the space around them (wave 0 at 5632, waves 1..7 from 13824).
+constexpr int LUT_LO = (127 - 17) << 7;           // bf16 bits of 2^-17
+constexpr int LUT_N = 22 * 128;                   // entries per sign
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+
+__device__ __forceinline__ void gelu_lut_fill(char* lut, int tid) {
+    for (int i = tid; i < 2 * LUT_N; i += 512) {
+        const int sgn = i >= LUT_N, k = i - sgn * LUT_N;
+        const unsigned bits = (unsigned)(LUT_LO + k) | ((unsigned)sgn << 15);
+        const float y = gelu_erf(__uint_as_float(bits << 16));
+        *(unsigned short*)(lut + sgn * 8192 + k * 2) = (unsigned short)(__builtin_bit_cast(unsigned short, f2bf(y)));
+    }
+}
+// packed pair of bf16 inputs -> packed pair of bf16 GELU values; mx accumulates the pair's window offsets (both halves)
+__device__ __forceinline__ unsigned gelu_lut_pair(unsigned pk, const char* lut, unsigned& mx) {
+    const u16x2_t d = __builtin_bit_cast(u16x2_t, pk) - u16x2_t{(unsigned short)LUT_LO, (unsigned short)LUT_LO};
+    const unsigned t = __builtin_bit_cast(unsigned, d);
+    const u16x2_t m = __builtin_bit_cast(u16x2_t, t & 0x7fff7fffu), mo = __builtin_bit_cast(u16x2_t, mx);
+    mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(m, mo));
+    const u16x2_t d2 = d << u16x2_t{1, 1};
+    const unsigned u = (__builtin_bit_cast(unsigned, d2) & 0x1ffe1ffeu) | ((t & 0x80008000u) >> 2);
+    const unsigned lo = *(const unsigned short*)(lut + (u & 0xffffu));
+    const unsigned hi = *(const unsigned short*)(lut + (u >> 16));
+    return lo | (hi << 16);
+}
+
 template <int EPI, bool F8 = false>
 __device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&bias_f)[4][4], const float (&scale_f)[4][4],
-                                            bool has_bias, char* buf, int lane, const float (&dq_f)[4][4], float dq_row) {
+                                            bool has_bias, char* buf, int lane, const float (&dq_f)[4][4], float dq_row, const char* lut = nullptr) {
     const int r = lane & 15, g = lane >> 4;
+    if (EPI == EPI_GELU && lut) {
+        unsigned mx = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float x[4] = {a[j][0], a[j][1], a[j][2], a[j][3]};
+            if (F8) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[e] *= dq_row * dq_f[j][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] += bias_f[j][e];           // -0.0f where there is no bias: x + -0 = x, bit for bit
+            typedef __attribute__((ext_vector_type(2))) float f32x2_;
+            const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{x[0], x[1]}, bf16x2));   // bf16(acc + bias)
+            const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{x[2], x[3]}, bf16x2));
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+            *(u32x2_*)(buf + r * 128 + (((j * 4 + g) ^ r) << 3)) = u32x2_{gelu_lut_pair(p0, lut, mx), gelu_lut_pair(p1, lut, mx)};
+        }
+        const bool out = (mx & 0xffffu) >= (unsigned)LUT_N || (mx >> 16) >= (unsigned)LUT_N;
+        if (__builtin_amdgcn_ballot_w64(out) == 0) return;        // wave-uniform; otherwise the formula below rewrites the slice
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         float x[4] = {a[j][0], a[j][1], a[j][2], a[j][3]};
@@ -99,10 +153,8 @@ __device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&b
 #pragma unroll
             for (int e = 0; e < 4; e++) x[e] *= dq_row * dq_f[j][e];
         }
-        if (has_bias) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) x[e] += bias_f[j][e];
-        }
+        for (int e = 0; e < 4; e++) x[e] += bias_f[j][e];               // -0.0f where there is no bias: x + -0 = x, bit for bit
         if (EPI == EPI_GELU || EPI == EPI_LS_RES) {          // bf16(acc + bias) is a value of its own before the next op
             round_pair_bf16(x[0], x[1], x[0], x[1]);
             round_pair_bf16(x[2], x[3], x[2], x[3]);
@@ -130,7 +182,7 @@ __device__ __forceinline__ bf16x8 read_chunk(const char* buf, int r, int c) {
 
 template <int EPI, bool F8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[8][4], char* stg, int row_base, int col0,
-                                              int lane) {
+                                              int lane, const char* lut = nullptr) {
     constexpr bool ADD_ROWS = (EPI == EPI_LS_RES || EPI == EPI_RES);
     const bool has_bias = p.bias != nullptr;
     const bool full_n = col0 + 64 <= p.N;
@@ -150,7 +202,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int n = col0 + j * 16 + (lane >> 4) * 4;
-            if (has_bias) {
+            if (!has_bias) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) bias_f[j][e] = -0.0f;      // the add stays unconditional (a select per element otherwise)
+            } else {
                 if (vec) {
                     const bf16x4 b = *(const bf16x4*)(p.bias + n);
 #pragma unroll
@@ -220,8 +275,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
 
     const int rin = lane >> 3, c = lane & 7, gn = col0 + c * 8;
     const bool vec_ok = gn + 8 <= p.N && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (p.ldr & 7) == 0;
-    // rows to add after the read-back (residual stream / position embedding), requested one slice ahead
-    bf16x8 radd[2], rnext[2];
+    // rows to add after the read-back (residual stream / position embedding), requested RPF slices ahead: a slice takes ~1.2 us and a
+    // load from HBM ~2 under load, so one slice of cover left every slice waiting for its rows
+    // (Measured null: three slices ahead instead of one, ls_res at N = 1024 K = 1024 0.154 -> 0.154 ms: not the rows' latency.)
+    constexpr int RPF = 1;                                  // slices of residual rows in flight ahead of the one being stored
+    bf16x8 rring[RPF + 1][2];
     auto row_of = [&](int mf, int it) { return row_base + mf * 16 + it * 8 + rin; };
     auto load_rows = [&](int mf, bf16x8 (&dst)[2]) {
 #pragma unroll
@@ -232,13 +290,16 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
         }
     };
     constexpr bool PRE = ADD_ROWS || EPI == EPI_PATCH;
-    if (PRE && vec_ok) load_rows(0, radd);
+    if (PRE && vec_ok) {
+#pragma unroll
+        for (int q = 0; q < RPF; q++) load_rows(q, rring[q]);
+    }
 #pragma unroll
     for (int mf = 0; mf < 8; mf++) {
-        char* buf = stg + (mf & 1) * 2048;
-        stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf));
+        char* buf = stg + (EPI == EPI_GELU ? 0 : (mf & 1) * 2048);      // the GELU instance's tables leave room for one slice per wave
+        stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf), lut);
         __builtin_amdgcn_wave_barrier();
-        if (PRE && vec_ok && mf + 1 < 8) load_rows(mf + 1, rnext);
+        if (PRE && vec_ok && mf + RPF < 8) load_rows(mf + RPF, rring[(mf + RPF) % (RPF + 1)]);
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int r = it * 8 + rin;
@@ -255,7 +316,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
                 } else if (PRE) {
                     bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(radd[it][e]) + bf2f(v[e]));
+                    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(rring[mf % (RPF + 1)][it][e]) + bf2f(v[e]));
                     __builtin_nontemporal_store(o, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 } else {
                     __builtin_nontemporal_store(v, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
@@ -271,7 +332,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (PRE) { radd[0] = rnext[0]; radd[1] = rnext[1]; }
     }
 }
 
@@ -400,6 +460,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     int a_sub = wm * 8 * 1024 + lane_off;                // + (i*2 + ksub) * 1024
     int b_sub = wn * 4 * 1024 + lane_off;                // + (j*2 + ksub) * 1024
     char* stg = smem + LDS_MAIN2 + wave * 4096;       // epilogue: two 2 KiB bf16 slices per wave
+    const char* lut = nullptr;
+    if (EPI == EPI_GELU) {                            // ... or the GELU tables and one slice per wave (layout at gelu_lut_fill)
+        lut = smem + LDS_MAIN2;
+        stg = smem + LDS_MAIN2 + (wave == 0 ? 2 * LUT_N : 8192 + 2 * LUT_N + (wave - 1) * 2048);
+    }
 
     f32x4 acc[8][4];
     bf16x8 ra[4][2];          // A fragments of the current quadrant row: [i][ksub]
@@ -449,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // ---- cold start (first tile of this workgroup only): K-tile 0 and U0, U1 of K-tile 1 issued, U0/U1 of K-tile 0 landed
     dma(p.A, qA[0], 0, 0, 0); dma(p.W, qB[0], 0, 0, 1); dma(p.W, qB[1], 0, 0, 2); dma(p.A, qA[1], 0, 0, 3);
     dma(p.A, qA[0], 1, 1, 0); dma(p.W, qB[0], 1, 1, 1);
+    if (EPI == EPI_GELU) gelu_lut_fill(smem + LDS_MAIN2, tid);      // under the cold-start fills; the barrier below publishes it
     WAIT_VM0();
     __builtin_amdgcn_s_barrier();
 
@@ -511,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----
         if (EPI == EPI_GELU_Q8) epilogue_gelu_q8(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
-        else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
+        else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane, lut);
 #ifdef CR_DIAG_STAMPS
         if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();
 #endif
