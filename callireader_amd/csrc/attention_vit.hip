@@ -126,6 +126,13 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     };
     f32x16 oacc[DB];
     float m_run, l_run;
+    f32x4 lsum = {0.f, 0.f, 0.f, 0.f};                      // lean sweep: row sums (softmax32)
+    bf16x8 sel;
+    {
+        const int sr_ = lane & 15, sj_ = lane >> 4;
+        const bf16 one = f2bf(((sr_ == 0 && !(sj_ & 1)) || (sr_ == 1 && (sj_ & 1))) ? 1.0f : 0.0f);
+        sel = bf16x8{one, one, one, one, one, one, one, one};
+    }
 
     // lane-constant pieces of the LDS addresses (attention.hip)
     const int k_lane_off = l31 * ROWB;
@@ -173,15 +180,22 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     // sweep, and the whole block then repeats the sweep in the exact rescaling form (exact_sweep below).  A per-tile check with an
     // in-loop fallback made hipcc copy the 32 accumulators twice per tile (40 v_mov_b64).
     auto softmax32 = [&](const f32x16& sc, unsigned* pk, float m2f) {
-        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2f));
             const float p1 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j + 1]), LOG2E, -m2f));
-            q0 += p0; q1 += p1;
             pk[j] = pack_bf16(p0, p1);
         }
-        l_run += q0 + q1;
+        // The row sums come off the matrix pipe: P (the bf16 values P.V multiplies by) as the B operand of two 16x16x32 MFMAs against a
+        // 0/1 matrix.  As that instruction reads it, lane l is column l & 15 with the k range 8 (l >> 4) .. + 7, and it holds query
+        // l & 31: k ranges 0 and 2 of column c belong to query c, ranges 1 and 3 to query c + 16 -- so row 0 of `sel` is 1 on ranges
+        // 0, 2 and row 1 on ranges 1, 3, and D[0][c] / D[1][c] (lanes 0..15, registers 0 / 1) accumulate the sums of queries c / c + 16.
+        // 36 v_add_f32 per tile become four MFMAs of 16 cycles: the vector pipe is the busy one here (77 % against the matrix pipe's 42).
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const u32x4_t pw = {pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]};
+            lsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, __builtin_bit_cast(bf16x8, pw), lsum, 0, 0, 0);
+        }
     };
     // the same block in the exact form: running maximum, rescale of O and l when it grows (only exact_sweep uses it)
     auto softmax32_exact = [&](const f32x16& sc, unsigned* pk) {
@@ -249,8 +263,12 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             pv32(vbuf, 0, pk0, oacc);
             if (decltype(exact)::value) softmax32_exact(s1, pk1); else softmax32(s1, pk1, m2f);
             pv32(vbuf, 1, pk1, oacc);
-            // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them.
+            // lgkmcnt(0) as well: hipcc waits for the tile's LAST V fragments behind the barrier (in front of the MFMA that takes them),
+            // and behind the barrier another wave's fill of this very buffer may already be landing -- from the vector L1 when a
+            // sibling block on the CU has just fetched the same rows: one wave's d >= 32 columns of one tile's share wrong, once in a
+            // few launches of 32 640 blocks (scripts/attn_det.py).
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
     };
@@ -262,7 +280,10 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     float l_tot;
     if constexpr (!EXACT) {
         sweep(std::false_type{});
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        {   // query q's sum: lane q & 15, register q >> 4; + 1 for the CLS key (exp(0))
+            const float v0 = __shfl(lsum[0], l31 & 15, 64), v1 = __shfl(lsum[1], l31 & 15, 64);
+            l_tot = 1.0f + (l31 < 16 ? v0 : v1);
+        }
         const int bad = __syncthreads_or(!(l_tot < 1.2676506002282294e30f));
         if (tid == 0) flags[((int64_t)batch * p.H + head) * gx + qb] = bad;
     } else {

@@ -504,6 +504,34 @@ def test_attention_vit_shape_far_above_the_reference_point(E):
     torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
 
 
+def test_attention_vit_launches_back_to_back_are_identical(E, monkeypatch):
+    """Every launch of attention_vit.hip on the same input gives the same bits, and they stay within one bf16 step of the generic
+    kernel's.  Launches go out back to back (no synchronisation in between): with four workgroups per CU a wave used to leave the
+    tile's closing barrier with its last V fragment reads still queued in the LDS, behind a sibling's fill of that very buffer -- one
+    wave's d >= 32 columns of one tile's share wrong, once in a few launches (8 launches x 3 rounds of 96 tiles caught it every time)."""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    Bn, S, H, D = 96, 1025, 16, 64
+    C3, C1 = 3 * H * D, H * D
+    qkv = torch.randn(Bn, S, C3, device=dev(), generator=g).bfloat16()
+    strides = [S * C3, C3, D, S * C3, C3, D, S * C3, C3, D, S * C1, C1, D]
+
+    def launch(o):
+        E.op_attention(qkv, qkv[:, :, C1:], qkv[:, :, 2 * C1:], o, strides, Bn, H, S, S, D, q_prescale=0.125)
+    monkeypatch.setenv('CR_VIT_ATTN', '0')
+    ref = torch.zeros(Bn, S, C1, device=dev(), dtype=torch.bfloat16)
+    launch(ref)
+    torch.cuda.synchronize()
+    monkeypatch.setenv('CR_VIT_ATTN', '1')
+    for _ in range(3):
+        outs = [torch.full((Bn, S, C1), 7.0, device=dev(), dtype=torch.bfloat16) for _ in range(8)]
+        for o in outs:
+            launch(o)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, outs[0])
+        assert float((outs[0].float() - ref.float()).abs().max()) <= 2 ** -7
+
+
 def test_attention_exact_identity_layout(E):
     """V = one-hot rows, uniform scores: output row = mean of V rows -> exact in bf16; catches V^T/tr-read mistakes."""
     Bn, S, H, D = 1, 64, 1, 64
@@ -550,3 +578,22 @@ def test_attention_softmax_spike(E):
     torch.cuda.synchronize()
     ref = _attn_ref(q.float()[:, None], k.float()[:, None], v.float()[:, None], False, 0, 1.0, 1.0)[:, 0]
     torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
+
+
+@pytest.mark.parametrize('epi', [1, 2])
+def test_gemm256_launches_back_to_back_are_identical(E, epi):
+    """The persistent 256x256 kernel keeps LDS-DMA in flight across raw barriers and (GELU) reads its table beside them: the same
+    launch issued back to back must give the same bits every time."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    M, N, K = 64575, 1024, 1024
+    A = (torch.rand(M, K, device=dev(), generator=g) * 2 - 1).bfloat16()
+    W = ((torch.rand(N, K, device=dev(), generator=g) * 2 - 1) * 0.05).bfloat16()
+    bias = (torch.rand(N, device=dev(), generator=g) * 0.1).bfloat16()
+    scale = (torch.rand(N, device=dev(), generator=g) * 0.1).bfloat16()
+    res = torch.rand(M, N, device=dev(), generator=g).bfloat16()
+    kw = dict(bias=bias, kernel=2) if epi == 1 else dict(bias=bias, scale=scale, res=res, kernel=2)
+    for _ in range(3):
+        outs = [E.op_gemm(epi, A, W, **kw) for _ in range(8)]
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, outs[0])
