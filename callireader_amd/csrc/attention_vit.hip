@@ -244,8 +244,10 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         const float m2f = m_run * LOG2E;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        for (int i = 0; i < NT; i++) {
-            const int cur = i & 1;
+        // two tiles per trip: the buffer a tile sits in is a compile-time constant, so its LDS offsets are instruction immediates
+        // (eight v_add_u32 per tile otherwise); NT is even
+        auto tile = [&](int i, auto cur_c) {
+            constexpr int cur = decltype(cur_c)::value;
             if (i + 1 < NT) {
                 if (++kt == NT) { kt = 0; seek(0); }         // the rotated sweep wraps once
                 stage(cur ^ 1);
@@ -254,10 +256,14 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             const char* vbuf = kbuf + TILE;
             // K.Q^T of both 32-key blocks, then block by block softmax -> P.V: hipcc runs block 0's P.V MFMAs under block 1's softmax.
             // (Measured null, same run: a hand interleave -- every MFMA of S1 and of P.V0 fenced together with a quarter of the other
-            // block's softmax -- 0.389 ms against 0.388 for this form; per wave-tile the vector pipe carries ~520 cycles of issue, the
-            // matrix pipe 512, and three waves per SIMD overlap them only to ~1290.)
+            // block's softmax.)
+            // The vector pipe is the busy unit (softmax): a wave in its softmax / P.V part outranks the waves that are issuing their
+            // eight K.Q^T MFMAs, which fit into the issue slots the vector work leaves.  Same run, 255 tiles: no priorities 1.399 ms,
+            // this 1.359, the reverse (K.Q^T high) 1.385, one static priority per workgroup parity 1.382.
+            if (!decltype(exact)::value) __builtin_amdgcn_s_setprio(0);
             const f32x16 s0 = qk32(kbuf, 0, qf);
             const f32x16 s1 = qk32(kbuf, 1, qf);
+            if (!decltype(exact)::value) __builtin_amdgcn_s_setprio(1);
             unsigned pk0[8], pk1[8];
             if (decltype(exact)::value) softmax32_exact(s0, pk0); else softmax32(s0, pk0, m2f);
             pv32(vbuf, 0, pk0, oacc);
@@ -270,6 +276,10 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             // few launches of 32 640 blocks (scripts/attn_det.py).
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+        for (int i = 0; i < NT; i += 2) {
+            tile(i, std::integral_constant<int, 0>{});
+            tile(i + 1, std::integral_constant<int, 1>{});
         }
     };
     // The lean sweep's verdict (NaN compares false: a non-finite row sum is flagged as well) goes to the block's flag word; flagged
@@ -280,6 +290,7 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     float l_tot;
     if constexpr (!EXACT) {
         sweep(std::false_type{});
+        __builtin_amdgcn_s_setprio(0);
         {   // query q's sum: lane q & 15, register q >> 4; + 1 for the CLS key (exp(0))
             const float v0 = __shfl(lsum[0], l31 & 15, 64), v1 = __shfl(lsum[1], l31 & 15, 64);
             l_tot = 1.0f + (l31 < 16 ? v0 : v1);
@@ -374,7 +385,6 @@ __global__ __launch_bounds__(256, 4) void vit_attn_kernel(const AttnParams p) {
     const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
     vit_attn_body<false>(p, pid % gx, (pid / gx) % gy, pid / (gx * gy), gx);
 }
-
 // One workgroup per tile: redo the (head, query block)s the lean sweep flagged (a score ~88 above the CLS key's: none on real pages).
 // The tile's H * nb flag words are fetched in ONE round trip (a loop of dependent one-word loads per (tile, head) cost 47 us per
 // 255-tile launch with nothing flagged).
