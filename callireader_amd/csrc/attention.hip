@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 
         // ---- S^T = K . Q^T for two 32-key blocks ----
         f32x16 sacc[2];
+        if (!SPLIT) __builtin_amdgcn_s_setprio(0);            // (attention_vit.hip: the softmax / P.V part outranks the K.Q^T MFMAs)
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         // A pair of scores is rounded to bf16 by ONE v_cvt_pk_bf16_f32 and stays packed until the exponentials; the
         // row maximum is taken on the raw accumulators (rounding is monotonic, so max(round(s)) = round(max(s))) with
         // v_max3_f32.  Masking only on tiles that need it.
+        if (!SPLIT) __builtin_amdgcn_s_setprio(1);
         const bool need_mask = (kt * 64 + 64 > Sk) || (CAUSAL && kt * 64 + 63 > q_pos0 + qb * 128 + wave * 32);
         unsigned ppk[2][8];                                   // P as packed bf16 pairs: the PV B-operand, 4 dwords per fragment
         // Lean form for unmasked tiles after the first (no mask, no divisor: the ViT): the reference point of exp(s - m)
@@ -285,20 +287,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         const float m2 = m_new * LOG2E;                       // exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp_f32
         const float alpha = rescale ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
         m_run = m_new;
-        // exponentials on pairs: packed fp32 math (v_pk_fma_f32 / v_pk_add_f32) halves the FMA and row-sum issue slots
-        f32x2_t psum2 = {0.f, 0.f};
-        const f32x2_t l2e = {LOG2E, LOG2E}, negm = {-m2, -m2};
+        // exponentials: plain fp32 FMAs and adds (packed v_pk_fma_f32 / v_pk_add_f32 issue slower beside MFMAs than the two they replace)
+        float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const f32x2_t sv = {lo_bf16(spk[kb][i]), hi_bf16(spk[kb][i])};
-                const f32x2_t arg = __builtin_elementwise_fma(sv, l2e, negm);
-                const f32x2_t pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-                psum2 += pv;
-                ppk[kb][i] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2));
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(lo_bf16(spk[kb][i]), LOG2E, -m2));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(hi_bf16(spk[kb][i]), LOG2E, -m2));
+                ps0 += p0; ps1 += p1;
+                ppk[kb][i] = pack_bf16(p0, p1);
             }
-        const float psum = psum2[0] + psum2[1];
+        const float psum = ps0 + ps1;
         l_run = l_run * alpha + psum;
         if (rescale) {
 #pragma unroll
