@@ -109,17 +109,14 @@ __device__ __forceinline__ void gelu_lut_fill(char* lut, int tid) {
         *(unsigned short*)(lut + sgn * 8192 + k * 2) = (unsigned short)(__builtin_bit_cast(unsigned short, f2bf(y)));
     }
 }
-// packed pair of bf16 inputs -> packed pair of bf16 GELU values; mx accumulates the pair's window offsets (both halves)
-__device__ __forceinline__ unsigned gelu_lut_pair(unsigned pk, const char* lut, unsigned& mx) {
+// packed pair of bf16 inputs -> the byte offsets of their table entries (low / high half); mx accumulates the pair's window offsets
+__device__ __forceinline__ unsigned gelu_lut_offsets(unsigned pk, unsigned& mx) {
     const u16x2_t d = __builtin_bit_cast(u16x2_t, pk) - u16x2_t{(unsigned short)LUT_LO, (unsigned short)LUT_LO};
     const unsigned t = __builtin_bit_cast(unsigned, d);
     const u16x2_t m = __builtin_bit_cast(u16x2_t, t & 0x7fff7fffu), mo = __builtin_bit_cast(u16x2_t, mx);
     mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(m, mo));
     const u16x2_t d2 = d << u16x2_t{1, 1};
-    const unsigned u = (__builtin_bit_cast(unsigned, d2) & 0x1ffe1ffeu) | ((t & 0x80008000u) >> 2);
-    const unsigned lo = *(const unsigned short*)(lut + (u & 0xffffu));
-    const unsigned hi = *(const unsigned short*)(lut + (u >> 16));
-    return lo | (hi << 16);
+    return (__builtin_bit_cast(unsigned, d2) & 0x1ffe1ffeu) | ((t & 0x80008000u) >> 2);
 }
 
 template <int EPI, bool F8 = false>
@@ -128,6 +125,7 @@ __device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&b
     const int r = lane & 15, g = lane >> 4;
     if (EPI == EPI_GELU && lut) {
         unsigned mx = 0;
+        unsigned short glo[4][2], ghi[4][2];                  // all sixteen gathers of the slice go out before the first is waited for
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float x[4] = {a[j][0], a[j][1], a[j][2], a[j][3]};
@@ -138,10 +136,20 @@ __device__ __forceinline__ void stage_slice(const f32x4 (&a)[4], const float (&b
 #pragma unroll
             for (int e = 0; e < 4; e++) x[e] += bias_f[j][e];           // -0.0f where there is no bias: x + -0 = x, bit for bit
             typedef __attribute__((ext_vector_type(2))) float f32x2_;
-            const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{x[0], x[1]}, bf16x2));   // bf16(acc + bias)
-            const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{x[2], x[3]}, bf16x2));
+            const unsigned pk[2] = {__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{x[0], x[1]}, bf16x2)),   // bf16(acc + bias)
+                                    __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{x[2], x[3]}, bf16x2))};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned u = gelu_lut_offsets(pk[h], mx);
+                glo[j][h] = *(const unsigned short*)(lut + (u & 0xffffu));
+                ghi[j][h] = *(const unsigned short*)(lut + (u >> 16));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
-            *(u32x2_*)(buf + r * 128 + (((j * 4 + g) ^ r) << 3)) = u32x2_{gelu_lut_pair(p0, lut, mx), gelu_lut_pair(p1, lut, mx)};
+            *(u32x2_*)(buf + r * 128 + (((j * 4 + g) ^ r) << 3)) =
+                u32x2_{(unsigned)glo[j][0] | ((unsigned)ghi[j][0] << 16), (unsigned)glo[j][1] | ((unsigned)ghi[j][1] << 16)};
         }
         const bool out = (mx & 0xffffu) >= (unsigned)LUT_N || (mx >> 16) >= (unsigned)LUT_N;
         if (__builtin_amdgcn_ballot_w64(out) == 0) return;        // wave-uniform; otherwise the formula below rewrites the slice
@@ -274,61 +282,132 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
     }
 
     const int rin = lane >> 3, c = lane & 7, gn = col0 + c * 8;
-    const bool vec_ok = gn + 8 <= p.N && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (p.ldr & 7) == 0;
-    // rows to add after the read-back (residual stream / position embedding), requested RPF slices ahead: a slice takes ~1.2 us and a
-    // load from HBM ~2 under load, so one slice of cover left every slice waiting for its rows
-    // (Measured null: three slices ahead instead of one, ls_res at N = 1024 K = 1024 0.154 -> 0.154 ms: not the rows' latency.)
-    constexpr int RPF = 1;                                  // slices of residual rows in flight ahead of the one being stored
-    bf16x8 rring[RPF + 1][2];
     auto row_of = [&](int mf, int it) { return row_base + mf * 16 + it * 8 + rin; };
-    auto load_rows = [&](int mf, bf16x8 (&dst)[2]) {
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int gm = min(row_of(mf, it), p.M - 1);
-            if (EPI == EPI_PATCH) dst[it] = *(const bf16x8*)(p.res + (int64_t)(1 + gm % p.group) * p.ldr + gn);
-            else dst[it] = *(const bf16x8*)(p.res + (int64_t)gm * p.ldr + gn);
-        }
-    };
     constexpr bool PRE = ADD_ROWS || EPI == EPI_PATCH;
-    if (PRE && vec_ok) {
+    // Fast path (wave-uniform): whole 64 columns inside N and 16-byte rows.  Its loop holds no other memory access than the rows'
+    // loads and the 16-byte stores, so hipcc counts its waits.  With the element-by-element fallback as a branch of the same loop
+    // it put s_waitcnt vmcnt(0) in front of every store: each slice then waited for the rows requested for the NEXT slices -- an
+    // HBM round trip per slice (in-kernel stamps, M = 64 575, N = K = 1024: the residual epilogue 22.6 k clocks against 6.9 k for a
+    // plain store) whatever the look-ahead.
+    const bool fast = full_n && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (!PRE || (p.ldr & 7) == 0);
+    if (fast && PRE && !F8 && row_base + 128 <= p.M) {
+        // Rows to add (residual stream, position embedding), interior tiles.  The counter loads and stores share only orders loads
+        // among loads and stores among stores, so with both in flight hipcc has to wait with vmcnt(0): the one-slice-ahead form of
+        // this loop (below; still used by the last, ragged row of tiles) waited an HBM round trip per slice -- 22.6 k clocks against
+        // 6.9 k for a plain store (in-kernel stamps at M = 64 575, N = K = 1024), the same with three slices ahead.  Here the rows of
+        // FOUR slices are requested together (one wave-uniform base per 8 rows + ONE per-lane offset: no address registers), the
+        // sums replace them in their registers, the first half's stores and the second half's requests go out back to back: two
+        // round trips per sub-tile instead of eight.
+        const uint32_t lane_off = (uint32_t)(((int64_t)rin * p.ldr + gn) * 2);
+        auto rows_at = [&](int mf, int it) -> const char* {
+            const int gm0 = row_base + mf * 16 + it * 8;                       // wave-uniform
+            const int64_t rrow = EPI == EPI_PATCH ? 1 + gm0 % p.group : gm0;    // (EPI_PATCH: 8 | group, a piece never wraps)
+            return (const char*)p.res + rrow * p.ldr * 2;
+        };
+        bf16x8 rr[4][2];
+        auto request = [&](int h) {
 #pragma unroll
-        for (int q = 0; q < RPF; q++) load_rows(q, rring[q]);
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int it = 0; it < 2; it++) rr[q][it] = *(const bf16x8*)(rows_at(4 * h + q, it) + lane_off);
+        };
+        auto send = [&](int h) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int gm = row_of(4 * h + q, it);
+                    int64_t orow = gm;
+                    if (EPI == EPI_PATCH) { const int t = gm / p.group; orow = (int64_t)t * (p.group + 1) + 1 + (gm - t * p.group); }
+                    __builtin_nontemporal_store(rr[q][it], (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
+                }
+        };
+        request(0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int mf = 4 * h + q;
+                char* buf = stg + (mf & 1) * 2048;
+                stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf), lut);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const bf16x8 v = read_chunk(buf, it * 8 + rin, c);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) rr[q][it][e] = f2bf(bf2f(rr[q][it][e]) + bf2f(v[e]));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            send(h);
+            if (h == 0) request(1);                          // behind the first half's stores: both kinds drain together, once
+        }
+        return;
     }
+    if (fast) {
+        constexpr int RPF = 1;                              // (e4m3 instance: no registers for more than one slice of rows ahead)
+        bf16x8 rring[RPF + 1][2];
+        auto load_rows = [&](int mf, bf16x8 (&dst)[2]) {
 #pragma unroll
-    for (int mf = 0; mf < 8; mf++) {
-        char* buf = stg + (EPI == EPI_GELU ? 0 : (mf & 1) * 2048);      // the GELU instance's tables leave room for one slice per wave
-        stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf), lut);
-        __builtin_amdgcn_wave_barrier();
-        if (PRE && vec_ok && mf + RPF < 8) load_rows(mf + RPF, rring[(mf + RPF) % (RPF + 1)]);
+            for (int it = 0; it < 2; it++) {
+                const int gm = min(row_of(mf, it), p.M - 1);
+                if (EPI == EPI_PATCH) dst[it] = *(const bf16x8*)(p.res + (int64_t)(1 + gm % p.group) * p.ldr + gn);
+                else dst[it] = *(const bf16x8*)(p.res + (int64_t)gm * p.ldr + gn);
+            }
+        };
+        if (PRE) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int r = it * 8 + rin;
-            const int gm = row_of(mf, it);
-            const bf16x8 v = read_chunk(buf, r, c);
-            if (gm >= p.M || gn >= p.N) continue;
-            int64_t orow = gm;
-            if (EPI == EPI_PATCH) { const int t = gm / p.group; orow = (int64_t)t * (p.group + 1) + 1 + (gm - t * p.group); }
-            if (vec_ok) {
+            for (int q = 0; q < RPF; q++) load_rows(q, rring[q]);
+        }
+#pragma unroll
+        for (int mf = 0; mf < 8; mf++) {
+            char* buf = stg + (EPI == EPI_GELU ? 0 : (mf & 1) * 2048);      // the GELU instance's tables leave room for one slice per wave
+            stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf), lut);
+            __builtin_amdgcn_wave_barrier();
+            if (PRE && mf + RPF < 8) load_rows(mf + RPF, rring[(mf + RPF) % (RPF + 1)]);
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int gm = row_of(mf, it);
+                const bf16x8 v = read_chunk(buf, it * 8 + rin, c);
+                int64_t orow = gm;
+                if (EPI == EPI_PATCH) { const int t = gm / p.group; orow = (int64_t)t * (p.group + 1) + 1 + (gm - t * p.group); }
                 if (EPI == EPI_F32) {
                     float* cp = (float*)p.C + orow * p.ldc + gn;
-                    *(f32x4*)cp = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
-                    *(f32x4*)(cp + 4) = f32x4{bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7])};
+                    if (gm < p.M) {
+                        *(f32x4*)cp = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+                        *(f32x4*)(cp + 4) = f32x4{bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7])};
+                    }
                 } else if (PRE) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(rring[mf % (RPF + 1)][it][e]) + bf2f(v[e]));
-                    __builtin_nontemporal_store(o, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
+                    if (gm < p.M) __builtin_nontemporal_store(o, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 } else {
-                    __builtin_nontemporal_store(v, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
+                    if (gm < p.M) __builtin_nontemporal_store(v, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 }
-            } else {                                          // ragged N or unaligned rows: element by element
-                for (int e = 0; e < 8 && gn + e < p.N; e++) {
-                    float x = bf2f(v[e]);
-                    if (ADD_ROWS) x = bf2f(p.res[(int64_t)gm * p.ldr + gn + e]) + x;
-                    if (EPI == EPI_PATCH) x = x + bf2f(p.res[(int64_t)(1 + gm % p.group) * p.ldr + gn + e]);
-                    if (EPI == EPI_F32) ((float*)p.C)[orow * p.ldc + gn + e] = x;
-                    else ((bf16*)p.C)[orow * p.ldc + gn + e] = f2bf(x);
-                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // ragged N or unaligned rows: element by element
+#pragma unroll
+    for (int mf = 0; mf < 8; mf++) {
+        char* buf = stg + (EPI == EPI_GELU ? 0 : (mf & 1) * 2048);
+        stage_slice<EPI, F8>(acc[mf], bias_f, scale_f, has_bias, buf, lane, dq_f, dq_row(mf), lut);
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 2; it++) {
+            const int gm = row_of(mf, it);
+            const bf16x8 v = read_chunk(buf, it * 8 + rin, c);
+            if (gm >= p.M || gn >= p.N) continue;
+            int64_t orow = gm;
+            if (EPI == EPI_PATCH) { const int t = gm / p.group; orow = (int64_t)t * (p.group + 1) + 1 + (gm - t * p.group); }
+            for (int e = 0; e < 8 && gn + e < p.N; e++) {
+                float x = bf2f(v[e]);
+                if (ADD_ROWS) x = bf2f(p.res[(int64_t)gm * p.ldr + gn + e]) + x;
+                if (EPI == EPI_PATCH) x = x + bf2f(p.res[(int64_t)(1 + gm % p.group) * p.ldr + gn + e]);
+                if (EPI == EPI_F32) ((float*)p.C)[orow * p.ldc + gn + e] = x;
+                else ((bf16*)p.C)[orow * p.ldc + gn + e] = f2bf(x);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -12,12 +12,13 @@ A = (torch.rand(M, K, device='cuda', generator=g) * 2 - 1).bfloat16()
 W = ((torch.rand(N, K, device='cuda', generator=g) * 2 - 1) * 0.05).bfloat16()
 bias = (torch.rand(N, device='cuda', generator=g) * 0.1).bfloat16()
 dbg = torch.zeros(256 * 2 * 32 * 4, device='cuda', dtype=torch.int64)
+res = torch.rand(M, N, device='cuda', generator=g).bfloat16() if epi == 3 else None
 for _ in range(20):
-    E.op_gemm(epi, A, W, bias=bias)
+    E.op_gemm(epi, A, W, bias=bias, res=res)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
-E.op_gemm(epi, A, W, bias=bias, scale=dbg)
+E.op_gemm(epi, A, W, bias=bias, scale=dbg, res=res)
 ev[1].record(); torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1])
 d = dbg.cpu().reshape(256, 2, 32, 4)
