@@ -42,4 +42,4 @@ for _ in range(3):
 vit, align, prefill, gen = best
 dec = (gen - prefill) / (new_tokens - 1)
 print(f'config 3: page ViT {vit:.1f} ms | char tiles ViT+resampler+VQ {align:.1f} ms | splice+prefill {prefill:.1f} ms | decode {dec:.3f} ms/token '
-      f'({14.72e9 / dec / 1e9:.0f} GB/s of weights) | page {1e-3 * (vit + align + prefill + dec * (new_tokens - 1)):.4f} s')
+      f'({14.72e3 / dec:.0f} GB/s of weights) | page {1e-3 * (vit + align + prefill + dec * (new_tokens - 1)):.4f} s')
