@@ -23,6 +23,10 @@
 
 #include "common.hpp"
 
+// gemm_stream.hip: X shared through LDS, waves split N (w1|w3, LM head at more than 16 rows); the same fp32 sums as launch_w's four-wave form
+bool gemm_stream_supported(int epi, const GemmParams& p, int splits);
+int launch_gemm_stream(int epi, const GemmParams& p, hipStream_t stream, int splits);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -333,6 +337,8 @@ bool gemm_skinny_supported(int epi, const GemmParams& p) {
 }
 
 int launch_gemm_skinny(int epi, const GemmParams& p, hipStream_t stream) {
+    static const bool stream_off = [] { const char* e = getenv("CR_SKINNY_OLD"); return e && e[0] == '1'; }();       // A/B aid
+    if (!stream_off && epi != EPI_PARTIAL && gemm_stream_supported(epi, p, 1)) return launch_gemm_stream(epi, p, stream, 1);
     switch (epi) {
         case EPI_STORE: return launch_w<EPI_STORE>(p, stream);
         case EPI_RES: return launch_w<EPI_RES>(p, stream);
