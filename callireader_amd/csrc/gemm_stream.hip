@@ -1,4 +1,4 @@
-// Weight-streaming GEMM for decode, second form:  C[M,N] = epi(X[M,K] . W[N,K]^T),  16 < M <= 64 rows, N > 8192, K % 1024 == 0, bf16 weights
+// Weight-streaming GEMM for decode, second form:  C[M,N] = epi(X[M,K] . W[N,K]^T),  16 < M <= 64 rows, N > 8192, K % 2048 == 0, bf16 weights
 // (w1|w3 and the LM head when more than 16 pages decode together).
 //
 // gemm_skinny.hip splits K over the waves of a workgroup, so a workgroup's 64 weight rows take the whole X (M x K) through the CU's
@@ -9,14 +9,14 @@
 //     accumulator chain restarts at every quarter of K and the quarters are added in ascending order, so every element is the same
 //     fp32 sum, bit for bit, as gemm_skinny.hip's, and a row's result does not depend on which of the two kernels its batch takes
 //     (tests/test_gpu_ops.py::test_gemm_skinny_swiglu_and_row_independence: 9 rows against 36);
-//   * X is shared: a 256-deep chunk of all M rows (<= 32 KiB) arrives ONCE per workgroup by LDS-DMA as 1-KiB fragment sub-tiles
+//   * X is shared: a 512-deep chunk of all M rows (<= 64 KiB) arrives ONCE per workgroup by LDS-DMA as 1-KiB fragment sub-tiles
 //     (16 rows x 32 k, gemm256's conflict-free image) into one of two buffers and is read back by every wave with ds_read_b128;
 //     X through the load path = 1 / NW of the other kernel's;
-//   * W goes straight to registers, non-temporal, the next chunk's eight 16-byte loads per lane in flight under the current chunk;
+//   * W goes straight to registers, non-temporal, the next chunk's sixteen 16-byte loads per lane in flight under the current chunk;
 //   * NW is chosen per shape so that the grid is a whole number of rounds of the CUs (w1|w3: 7 waves -> 256 workgroups);
 //   * epilogues straight from the accumulators (C^T tile: lane = 4 consecutive n of one m): store / +residual / fp32 logits with
 //     the reference's rounding points, SwiGLU (rows [8 gate | 8 up] of a tile meet through one lane exchange).
-// Measured at 64 rows (scripts/skinny_bench.py): w1|w3 73.5 -> 59.2 us.  The K-sliced partial-sum GEMMs (wqkv, wo, w2) gained 1-3 us
+// Measured at 64 rows (scripts/skinny_bench.py): w1|w3 73.5 -> 56.6 us.  The K-sliced partial-sum GEMMs (wqkv, wo, w2) gained 1-3 us
 // in this form and lost 1-2 us at one row (a wave walking a whole slice alone keeps fewer loads in flight than eight waves
 // splitting it), so they stay with gemm_skinny.hip; so does everything up to 16 rows (w1|w3 at one row: 46 us there, 52 here).
 #include <stdlib.h>
@@ -28,14 +28,15 @@ namespace {
 template <int EPI, int MT, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p, const int ks_len, const int fold) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SUBS = MT * 8;                     // 1-KiB sub-tiles (16 rows x 32 k) of a 256-deep chunk
+    constexpr int KSC = 16;                          // k-steps of 32 per chunk: 512-deep chunks (256-deep ones, a round trip per 256 k: w1|w3 at 64 rows 59.1 us against 56.6)
+    constexpr int SUBS = MT * KSC;                   // 1-KiB sub-tiles (16 rows x 32 k) of a chunk
     constexpr int CH = SUBS * 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = ((int)blockIdx.x * NW + wave) * 16;
     const int split = blockIdx.y;
     const int k0 = split * ks_len;
-    const int chunks = ks_len >> 8;
+    const int chunks = ks_len / (32 * KSC);
 
     const bf16* wp = p.W + (int64_t)min(n0 + (lane & 15), p.N - 1) * p.ldw + k0 + (lane >> 4) * 8;
     // X staging: sub-tile s = (row tile s >> 3, k-step s & 7); wave w brings s = w, w + NW, ...; lane -> row lane >> 2 of the
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     const int srow = lane >> 2, schunk = (lane & 3) ^ ((srow >> 3) << 1);
     auto stage = [&](int buf, int c) {
         for (int s = wave; s < SUBS; s += NW) {
-            const int t = s >> 3, ks = s & 7;
-            const bf16* src = p.A + (int64_t)min(t * 16 + srow, p.M - 1) * p.lda + k0 + c * 256 + ks * 32 + schunk * 8;
+            const int t = s / KSC, ks = s % KSC;
+            const bf16* src = p.A + (int64_t)min(t * 16 + srow, p.M - 1) * p.lda + k0 + c * (32 * KSC) + ks * 32 + schunk * 8;
             __builtin_amdgcn_global_load_lds(CR_GLB(src), CR_LDS(smem + buf * CH + s * 1024), 16, 0, 0);
         }
     };
@@ -54,20 +55,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wa[8], wb[8];
+    bf16x8 wa[KSC], wb[KSC];
     auto loadw = [&](bf16x8* w, int c) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) w[ks] = __builtin_nontemporal_load((const bf16x8*)(wp + c * 256 + ks * 32));
+        for (int ks = 0; ks < KSC; ks++) w[ks] = __builtin_nontemporal_load((const bf16x8*)(wp + c * (32 * KSC) + ks * 32));
     };
     f32x4 tot[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf, const bf16x8* w) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++)
+        for (int ks = 0; ks < KSC; ks++)
 #pragma unroll
             for (int t = 0; t < MT; t++) {
-                const bf16x8 xf = *(const bf16x8*)(smem + buf * CH + (t * 8 + ks) * 1024 + lane_off);
+                const bf16x8 xf = *(const bf16x8*)(smem + buf * CH + (t * KSC + ks) * 1024 + lane_off);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks], xf, acc[t], 0, 0, 0);
             }
     };
@@ -139,11 +140,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
 
 template <int EPI, int MT, int NW>
 int launch_nw(const GemmParams& p, hipStream_t stream, int splits) {
-    constexpr int LDS = 2 * MT * 8 * 1024;
+    constexpr int LDS = 2 * MT * 16 * 1024;
     static std::atomic<uint64_t> attr_done{0};
     if (!cr_dyn_lds_once(attr_done, (const void*)gemm_stream_kernel<EPI, MT, NW>, LDS)) return CR_ERR_HIP;
     const dim3 grid((p.N + 16 * NW - 1) / (16 * NW), splits);
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, NW>), grid, dim3(NW * 64), LDS, stream, p, p.K / splits, p.K / splits / 1024);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, NW>), grid, dim3(NW * 64), LDS, stream, p, p.K / splits, p.K / splits / 2048);      // chunks per quarter of K
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
@@ -192,7 +193,7 @@ int gemm_stream_waves(int N, int splits) {
 
 bool gemm_stream_supported(int epi, const GemmParams& p, int splits) {
     // exactly the launches gemm_skinny.hip would run with FOUR waves over K and whose quarters are whole 256-deep chunks
-    if (p.w8 || p.a8 || p.M <= 16 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 1024 != 0) return false;
+    if (p.w8 || p.a8 || p.M <= 16 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0) return false;
     if ((p.lda & 7) || (p.ldw & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;
