@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid: A/B of vit_attn_kernel experiment variants (CR_VIT_ATTN=1,3..7) in one process, interleaved rounds."""
+"""Development aid: A/B of the ViT attention launch under CR_VIT_ATTN values (1 = attention_vit.hip, 0 = the generic kernel; experiment builds add more) in one process, interleaved rounds, 63 and 255 tiles."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +18,7 @@ for Bn in (63, 255):
     o = torch.zeros(Bn, S, H * D, device='cuda', dtype=torch.bfloat16)
     C3, C1 = 3 * H * D, H * D
     run = lambda: E.op_attention(qkv, qkv[:, :, C1:], qkv[:, :, 2 * C1:], o, [S * C3, C3, D, S * C3, C3, D, S * C3, C3, D, S * C1, C1, D], Bn, H, S, S, D, q_prescale=0.125)
-    names = sys.argv[1].split(',') if len(sys.argv) > 1 else ['1', '3', '4', '5', '6', '7']
+    names = sys.argv[1].split(',') if len(sys.argv) > 1 else ['1', '0']
     res = {n: [] for n in names}
     outs = {}
     for rnd in range(5):
