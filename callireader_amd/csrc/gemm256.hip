@@ -289,7 +289,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
     // it put s_waitcnt vmcnt(0) in front of every store: each slice then waited for the rows requested for the NEXT slices -- an
     // HBM round trip per slice (in-kernel stamps, M = 64 575, N = K = 1024: the residual epilogue 22.6 k clocks against 6.9 k for a
     // plain store) whatever the look-ahead.
-    const bool fast = full_n && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (!PRE || (p.ldr & 7) == 0);
+    const bool fast = full_n && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (!PRE || ((p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0));
     if (fast && PRE && !F8 && row_base + 128 <= p.M) {
         // Rows to add (residual stream, position embedding), interior tiles.  The counter loads and stores share only orders loads
         // among loads and stores among stores, so with both in flight hipcc has to wait with vmcnt(0): the one-slice-ahead form of
