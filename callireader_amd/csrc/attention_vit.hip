@@ -7,13 +7,16 @@
 //   * the 1024 PATCH queries form 8 full blocks of 128 and sweep the 1024 PATCH keys as 16 full tiles of 64: no padding, no masks;
 //   * the CLS KEY enters each query's softmax as the INITIAL state instead of a tile: s0 = q . k_cls by 32 FMAs per lane, the
 //     reference point of the exponentials m = bf16(s0), row sum 1, O = v_cls -- so every tile of the sweep takes the lean softmax
-//     path (attention.hip) from the first one on; a score ~42 above that point in any lane falls back to the exact rescaling form;
+//     path (attention.hip) from the first one on; a row sum that is not finite or >= 2^100 at the END of the sweep (a score ~88 above
+//     that point) flags the block, and vit_attn_exact_kernel redoes flagged blocks in the exact rescaling form;
 //   * the CLS QUERY is spread over all workgroups of its (tile, head): block b sweeps its key tiles in the rotated order
 //     2b+2, ..., 2b+1 (a softmax does not care; it also spreads the eight blocks' K/V fetches over the tiles), so its LAST two tiles
 //     are 2b and 2b+1 and are both still in LDS when the sweep ends; each of the four waves then takes one 32-key half of them for the
 //     CLS query (4 + 4 MFMAs, exact softmax) and writes an un-normalised partial (m, l, O[64]); vit_cls_combine_kernel merges the
 //     4n + 1 partials (the +1: the CLS key itself, by block 0) in index order, like the decode path's split combine.
 // Work per (tile, head): 8 x 16.6 tile-times instead of 9 x 17.
+// The sweep is bound by the vector pipe (77 % busy against 42 % for the matrix pipe: the reference's own per-score arithmetic), so: 124
+// registers = four waves per SIMD, row sums on the matrix pipe, two tiles per loop trip, the softmax part at priority 1, no SLP packing.
 #include <stdlib.h>
 
 #include <type_traits>
