@@ -68,6 +68,26 @@ def build_ids(n_page_tiles, n_char_tiles, text_tokens, img_id, ref_id, seed):
     return torch.cat([head, torch.full((n_page_tiles * 256,), img_id), torch.full((n_char_tiles * 3,), ref_id), tail])
 
 
+def plan_workload(scaling, pages, total_pages, world, rank):
+    """Which pages and which character tiles one rank handles in a step.  weak: `pages` per GPU whatever N (n_pages = pages * world);
+    strong: `total_pages` per step over all ranks (BASELINE config 4 as written: 64 pages over 8 GPUs).  Pages are owned round-robin,
+    the flat list of character tiles is split contiguously and evenly (callireader_amd/parallel.py).  Pure host arithmetic."""
+    from callireader_amd.parallel import shard_range, owned_pages
+    if scaling not in ('weak', 'strong'):
+        raise ValueError(scaling)
+    n_pages = total_pages if scaling == 'strong' else pages * world
+    if n_pages < world:
+        raise SystemExit(f'{n_pages} pages per step < {world} ranks: every rank needs a page')
+    mine = owned_pages(n_pages, world, rank)
+    ct_lo, ct_hi = shard_range(n_pages * CHAR_TILES, world, rank)
+    return {'scaling': scaling, 'n_pages': n_pages, 'mine': mine, 'ct_lo': ct_lo, 'ct_hi': ct_hi, 'pages_per_gpu': len(mine)}
+
+
+# the one whole-page CPU measurement on record (profiles/round3/01_bench_N1_default_full_cpu_baseline.json, AMD EPYC 9575F, 64 threads): the
+# sampled extrapolation of the same run said 165 s per page, the oracle measured stage by stage took 231 s
+CPU_FULL_PAGE_MEASURED_S, CPU_FULL_PAGE_SAMPLED_S = 231.0, 165.0
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference's eager path) on a bounded sample of the same page workload,
     extrapolated linearly to one page.  Reported next to the GPU number; it is not the target."""
@@ -108,8 +128,13 @@ def cpu_baseline():
         t_dec = (time.time() - t0) / 4 * dims.llm_layers                           # s per new token, 32 layers
     S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
     page_s = t_vit * (PAGE_TILES + CHAR_TILES) + t_rs * CHAR_TILES + t_pre * S_page + t_dec * NEW_TOKENS
+    ratio = CPU_FULL_PAGE_MEASURED_S / CPU_FULL_PAGE_SAMPLED_S
     return {'value': 1.0 / page_s, 'unit': 'pages/s', 'cores': cores, 'kind': 'port',
-            'cpu': platform.processor() or platform.machine(), 'host_cores': os.cpu_count(),
+            'cpu': _cpu_model(), 'host_cores': os.cpu_count(),
+            'measured_over_sampled': round(ratio, 2), 'value_calibrated': 1.0 / (page_s * ratio),
+            'calibration': (f'the sample under-states a page: the one whole-page run on record (--cpu-baseline full, EPYC 9575F, 64 threads, profiles/round3/'
+                            f'01_bench_N1_default_full_cpu_baseline.json) measured {CPU_FULL_PAGE_MEASURED_S:.0f} s per page where its own sample said '
+                            f'{CPU_FULL_PAGE_SAMPLED_S:.0f} s; value_calibrated = value / {ratio:.2f}'),
             'sample': (f'oracle bf16 eager: ViT+mlp1 24 layers on 2 tiles ({t_vit:.2f} s/tile), resampler 1 of 4 layers on 2 tiles, '
                        f'InternLM2 1 of 32 layers prefill {S} tokens ({t_pre * 1e3:.1f} ms/token x32) + 4 decode steps '
                        f'({t_dec * 1e3:.0f} ms/token x32); extrapolated linearly to one page (107 tiles, {S_page} prompt tokens, '
@@ -133,6 +158,8 @@ def measure_traffic(pages=16):
     args = ['--steps', '1', '--warmup', '0', '--pages', str(pages), '--new-tokens', '2', '--no-cpu-baseline', '--no-vit-extra', '--no-pipeline', '--no-traffic']
     work = tempfile.mkdtemp(prefix='cr_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
+        env.pop(k, None)                                      # the children are one-process runs whatever launched this one
     sums = {}
     try:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -239,6 +266,10 @@ def main():
                     help='sample: bounded sample extrapolated to one page (default, ~15 s); full: the oracle on ONE WHOLE example-shaped page (107 tiles, 24 + 4 + 32 layers, '
                          '3164-token prefill, 8 decode steps; minutes of host time and ~25 GB of host memory), printed next to the extrapolation')
     ap.add_argument('--no-vit-extra', action='store_true')
+    ap.add_argument('--no-strong-block', action='store_true',
+                    help='N > 1 with weak scaling: do not append the strong-scaling block (BASELINE config 4 as written: --total-pages per step over all ranks) to the line')
+    ap.add_argument('--strong-steps', type=int, default=2, help='timed steps of that block')
+    ap.add_argument('--fp8-extras', action='store_true', help='also time the batched decode on e4m3 weight copies (fp8_decode; 1.03-1.09x at 64 rows, so not in the default line)')
     ap.add_argument('--no-pipeline', action='store_true', help='one batch at a time (the decode of a batch does not run beside the visual stage of the next)')
     args = ap.parse_args()
     NEW_TOKENS = args.new_tokens
@@ -272,10 +303,9 @@ def main():
     from callireader_amd.parallel import shard_range, all_gather_rows_async, owned_pages
 
     dims = ModelDims.full()
-    n_pages = args.total_pages if args.scaling == 'strong' else args.pages * world
-    if n_pages < world:
-        raise SystemExit(f'--total-pages {n_pages} < {world} ranks: every rank needs a page')
-    P = len(owned_pages(n_pages, world, rank))           # pages this rank owns per step (round-robin; = --pages with weak scaling)
+    wl = plan_workload(args.scaling, args.pages, args.total_pages, world, rank)
+    n_pages, mine, ct_lo, ct_hi = wl['n_pages'], wl['mine'], wl['ct_lo'], wl['ct_hi']
+    P = wl['pages_per_gpu']                              # pages this rank owns per step (round-robin; = --pages with weak scaling)
     S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
     model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=S_page + NEW_TOKENS + 64, max_pages=P)
     model.img_context_token_id = IMG_CONTEXT_TOKEN_ID
@@ -284,14 +314,20 @@ def main():
     # ---- synthetic inputs, resident in HBM ----
     # character tiles (90 % of the visual work) are sharded evenly over all ranks whatever page they belong to;
     # page tiles stay with the page's owner: their embeddings are 2.1 MB per tile and nobody else needs them
-    mine = owned_pages(n_pages, world, rank)
-    ct_lo, ct_hi = shard_range(n_pages * CHAR_TILES, world, rank)
-    page_px = synthetic.make_pixels(len(mine) * PAGE_TILES, seed=10 + rank, device=dev)
-    char_px = synthetic.make_pixels(ct_hi - ct_lo, seed=20 + rank, device=dev)
-    ids = [build_ids(PAGE_TILES, CHAR_TILES, TEXT_TOKENS, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, 1000 + p).to(dev) for p in mine]
+    def make_inputs(w):
+        return (synthetic.make_pixels(len(w['mine']) * PAGE_TILES, seed=10 + rank, device=dev),
+                synthetic.make_pixels(w['ct_hi'] - w['ct_lo'], seed=20 + rank, device=dev),
+                [build_ids(PAGE_TILES, CHAR_TILES, TEXT_TOKENS, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, 1000 + p).to(dev) for p in w['mine']])
+    page_px, char_px, ids = make_inputs(wl)
+    headline_inputs = (page_px, char_px, ids)
 
-    def step(new_tokens=None, stamps=None):
+    def step(new_tokens=None, stamps=None, w=None, inputs=None):
         new_tokens = NEW_TOKENS if new_tokens is None else new_tokens
+        if w is not None:                                 # another workload than the headline's (the strong-scaling block)
+            n_pages, mine = w['n_pages'], w['mine']
+            page_px, char_px, ids = inputs
+        else:
+            n_pages, mine, page_px, char_px, ids = wl['n_pages'], wl['mine'], *headline_inputs
         pseudo_local, _ = model.align_tiles(char_px)                                 # (3 * my char-tile shard, 4096)
         gathered = all_gather_rows_async(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile, over xGMI ...
         vit_mine = model.extract_feature(page_px)                                    # ... underneath the owner's page tiles (my pages * 11, 256, 4096)
@@ -388,24 +424,24 @@ def main():
         elapsed = float(t.item())
 
     # the path's one collective, alone on the wire (untimed extra): the pseudo-token all-gather of one step
-    gather = None
-    if world > 1:
-        rows = torch.zeros(ct_hi - ct_lo, 3, dims.llm_hidden, device=dev, dtype=torch.bfloat16)
-        all_gather_rows_async(rows, n_pages * CHAR_TILES)()
+    def gather_standalone(w):
+        rows = torch.zeros(w['ct_hi'] - w['ct_lo'], 3, dims.llm_hidden, device=dev, dtype=torch.bfloat16)
+        all_gather_rows_async(rows, w['n_pages'] * CHAR_TILES)()
         sync()
         ts = []
         for _ in range(5):
             t0 = time.perf_counter()
-            all_gather_rows_async(rows, n_pages * CHAR_TILES)()
+            all_gather_rows_async(rows, w['n_pages'] * CHAR_TILES)()
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         sync()
         ms = sorted(ts)[2] * 1e3
-        total_bytes = n_pages * CHAR_TILES * 3 * dims.llm_hidden * 2
-        gather = {'collective': 'all_gather_into_tensor (pseudo-token embeddings of the character tiles)', 'backend': dist.get_backend(),
-                  'bytes_per_rank_sent': (ct_hi - ct_lo) * 3 * dims.llm_hidden * 2, 'bytes_gathered': total_bytes,
-                  'standalone_ms': round(ms, 3), 'gb_per_s_received': round(total_bytes * (world - 1) / world / (ms * 1e-3) / 1e9, 1),
-                  'note': 'inside a step the gather runs underneath the page tiles\' ViT (all_gather_rows_async)'}
+        total_bytes = w['n_pages'] * CHAR_TILES * 3 * dims.llm_hidden * 2
+        return {'collective': 'all_gather_into_tensor (pseudo-token embeddings of the character tiles)', 'backend': dist.get_backend(),
+                'bytes_per_rank_sent': (w['ct_hi'] - w['ct_lo']) * 3 * dims.llm_hidden * 2, 'bytes_gathered': total_bytes,
+                'standalone_ms': round(ms, 3), 'gb_per_s_received': round(total_bytes * (world - 1) / world / (ms * 1e-3) / 1e9, 1),
+                'note': 'inside a step the gather runs underneath the page tiles\' ViT (all_gather_rows_async)'}
+    gather = gather_standalone(wl) if world > 1 else None
 
     # one un-pipelined step for comparison (untimed extra) and a self-check: the pipelined run's ids are the sequential step's
     seq_ms, same_ids, seq_frac, seq_dec = None, None, None, None
@@ -440,6 +476,43 @@ def main():
                    'visual_ms': round((st[1] - st[0]) * 1e3, 1), 'prefill_ms': round((st[2] - st[1]) * 1e3, 1),
                    'tflops': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12, 1),
                    'mfma_frac': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    # ---- N > 1, weak scaling (what the driver's one command runs): BASELINE config 4 AS WRITTEN in the same process group ----
+    # `--total-pages` per step over ALL ranks (64 pages over 8 GPUs = 8 per GPU): the number north_star's ">= 6x at 8 GPUs" is about.  Weak scaling
+    # is >= 6x almost by construction (the one collective is 24.5 KB per character tile); strong scaling carries the Amdahl term of the
+    # small-batch decode.  One batch at a time (8 pages per GPU leave a second batch nothing to hide behind), untimed warm-up step, then
+    # --strong-steps timed steps between barriers, MAX over ranks; phases from one extra stamped pass.
+    strong = None
+    if world > 1 and args.scaling == 'weak' and not args.no_strong_block:
+        ws = plan_workload('strong', args.pages, args.total_pages, world, rank)
+        ins = make_inputs(ws)
+        step(w=ws, inputs=ins)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.strong_steps):
+            step(w=ws, inputs=ins)
+        sync()
+        el = time.perf_counter() - t0
+        st2 = [0.0]
+        sync(); st2[0] = time.perf_counter()
+        step(new_tokens=1, stamps=st2, w=ws, inputs=ins)
+        sync()
+        t = torch.tensor([el, st2[1] - st2[0], st2[2] - st2[1]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, vis_s, pre_s = (float(x) for x in t.tolist())
+        g2 = gather_standalone(ws)
+        per_step = el / args.strong_steps
+        strong = {'what': 'BASELINE config 4 as written: the pages of a step are divided over the ranks (strong scaling), one batch at a time, in the same process group '
+                          'as the weak-scaling line above',
+                  'scaling': 'strong', 'pages_per_step': ws['n_pages'], 'pages_per_gpu': ws['pages_per_gpu'], 'char_tiles_this_rank': ws['ct_hi'] - ws['ct_lo'],
+                  'steps': args.strong_steps, 'value': round(ws['n_pages'] / per_step, 4), 'unit': 'pages/s', 'ms_per_step': round(per_step * 1e3, 2),
+                  'phases_ms': {'visual_incl_all_gather': round(vis_s * 1e3, 1), 'splice_prefill_first_token': round(pre_s * 1e3, 1),
+                                'decode_remaining_tokens': round(max(per_step - vis_s - pre_s, 0.0) * 1e3, 1),
+                                'how': 'MAX over ranks of one extra stamped pass that stops after the first token; decode = timed step - those two'},
+                  'all_gather': g2,
+                  'n1_denominator': f'the N = 1 default line IS this configuration at one GPU when --pages = --total-pages ({args.pages} vs {ws["n_pages"]}): '
+                                    'speed-up = this value / that value; no speed-up is printed here because this run did not measure N = 1'}
+        del ins
 
     result = None
     if rank == 0:
@@ -488,6 +561,7 @@ def main():
             'prof_truncated': bool(pstat[2] != 0 or pstat[0] != pstat[1] or int(big_n + sm_n) != pstat[0]),
             'prof': {'launches_bracketed': int(pstat[0]), 'accounted': int(pstat[1]), 'lost': int(pstat[2]), 'peak_pending': int(pstat[3])},
             'all_gather': gather,
+            'strong_scaling': strong,
             'pipeline': None if pipe is None else {
                 'what': 'two batches in flight (PagePipeline): a worker thread runs the HBM-bound batched decode of batch i-1 on a second HIP stream '
                         '(second context sharing the weights) beside the matrix-bound visual stage and prefill of batch i; a run of K steps ends '
@@ -607,13 +681,14 @@ def main():
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n_steps
                 return dt, first, [kv.generated(i)[:n_steps + 2] for i in live]
-            dt16, lg16, ids16 = decode_run()
-            eng.enable_fp8_decode(True)
-            decode_run(4)
-            dt8, lg8, ids8 = decode_run()
-            eng.enable_fp8_decode(False)
-            same = sum(a == b for x, y in zip(ids16, ids8) for a, b in zip(x[:2], y[:2]))
-            result['fp8_decode'] = {'what': 'batched greedy decode with e4m3 copies of the LLM linear weights (one fp32 scale per output row, dequantised '
+            if args.fp8_extras:
+              dt16, lg16, ids16 = decode_run()
+              eng.enable_fp8_decode(True)
+              decode_run(4)
+              dt8, lg8, ids8 = decode_run()
+              eng.enable_fp8_decode(False)
+              same = sum(a == b for x, y in zip(ids16, ids8) for a, b in zip(x[:2], y[:2]))
+              result['fp8_decode'] = {'what': 'batched greedy decode with e4m3 copies of the LLM linear weights (one fp32 scale per output row, dequantised '
                                             'in registers, same bf16 MFMA, fp32 accumulation; activations / KV cache / prefill / vision stay bf16) '
                                             'next to the bf16 path on the same pages: an option, not the headline',
                                     'pages': len(embeds), 'bf16_ms_per_step': round(dt16 * 1e3, 3), 'fp8_ms_per_step': round(dt8 * 1e3, 3),

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "attention.hpp"
 #include <stdlib.h>
 
@@ -112,8 +114,8 @@ int ctx_gemm(cr_ctx* c, int epi, const GemmParams& p, hipStream_t st) {
 static size_t dtype_size(int dt) { return dt == CR_BF16 ? 2 : dt == CR_F32 ? 4 : dt == CR_I64 ? 8 : dt == CR_I32 ? 4 : 0; }   // CR_U8 is internal: not loadable
 
 int ctx_share_ok(const cr_ctx* c, const char* who) {
-    if (c->borrowed && c->owner && c->owner->weight_gen != c->owner_gen)
-        return cr_fail(CR_ERR_STATE, "%s: the context that owns these weights reloaded, re-finalized or switched an fp8 option since cr_share_weights: share again", who);
+    if (c->borrowed && c->owner_cell && c->owner_cell->load(std::memory_order_acquire) != c->owner_gen)
+        return cr_fail(CR_ERR_STATE, "%s: the context that owns these weights was destroyed, reloaded, re-finalized or switched an fp8 option since cr_share_weights: share again", who);
     return CR_OK;
 }
 
@@ -146,6 +148,7 @@ int cr_destroy(cr_ctx* c) {
     if (!c) return CR_OK;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    c->gen_cell->store(~(uint64_t)0, std::memory_order_release);      // borrowers of this context's tensors now fail ctx_share_ok instead of reading freed memory
     if (!c->borrowed) for (auto& kv : c->w) if (kv.second.ptr) hipFree(kv.second.ptr);
     if (c->ws) hipFree(c->ws);
     if (c->scratch) hipFree(c->scratch);
@@ -161,13 +164,16 @@ int cr_share_weights(cr_ctx* dst, const cr_ctx* src) {
     if (dst->device != src->device) return cr_fail(CR_ERR_ARG, "cr_share_weights: contexts on different devices");
     if (!dst->w.empty() && !dst->borrowed) return cr_fail(CR_ERR_STATE, "cr_share_weights: the destination owns weights of its own");
     if (!src->finalized) return cr_fail(CR_ERR_STATE, "cr_share_weights: finalize the source first");
+    if (ctx_share_ok(src, "cr_share_weights (source)") != CR_OK) return CR_ERR_STATE;      // a stale borrower hands on nothing
     dst->w = src->w;                    // device pointers only: nothing is copied
     dst->borrowed = true;
     dst->d = src->d;
     dst->finalized = true;
     dst->fp8_decode = src->fp8_decode; dst->fp8_mfma = src->fp8_mfma;
-    dst->owner = src; dst->owner_gen = src->weight_gen;
-    dst->weight_gen++;
+    // the cell of the context that owns the tensors: the source's own, or (source = a borrower) the one the source watches
+    dst->owner_cell = src->borrowed ? src->owner_cell : src->gen_cell;
+    dst->owner_gen = src->borrowed ? src->owner_gen : src->weight_gen;
+    cr_bump_gen(dst);
     return CR_OK;
 }
 
@@ -192,7 +198,7 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
     CR_HIP(hipMemcpyAsync(t.ptr, src, t.bytes, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (src_is_host) CR_HIP(hipStreamSynchronize((hipStream_t)stream));   // caller may free host memory right away
     c->w[name] = t;
-    c->weight_gen++;
+    cr_bump_gen(c);
     if (strncmp(name, "orderformer.", 12) != 0) c->finalized = false;      // the sorter (f4) has no derived tensors to refresh
     return CR_OK;
 }
@@ -292,17 +298,24 @@ int cr_op_attention(const void* q, const void* k, const void* v, void* o, const 
     p.q_prescale = q_prescale; p.s_div = s_div;
     if (!causal && head_dim == 64 && Sq == Sk && Sq > 256 && ((Sq - 1) & 127) == 0 && s_div == 1.0f && kv_group == 1) {
         // the ViT layout takes attention_vit.hip, which wants scratch for the CLS query's partials: this test / profiling entry point
-        // keeps one grow-only buffer per process (stage entry points carve theirs out of the context's workspace)
-        static float* scratch = nullptr;
-        static size_t scratch_n = 0;
+        // keeps one grow-only buffer per DEVICE (stage entry points carve theirs out of the context's workspace); growing waits for the
+        // device first, and the lock makes concurrent callers take turns (the kernels of one device's callers share the buffer: this
+        // entry point is for one caller per device at a time, as the header says)
+        static std::mutex mu;
+        static float* scratch[64] = {};
+        static size_t scratch_n[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return cr_fail(CR_ERR_HIP, "cr_op_attention: device");
         const size_t need = vit_attn_ws_floats(B, H, Sq);
-        if (need > scratch_n) {
-            if (scratch) hipFree(scratch);
-            scratch = nullptr; scratch_n = 0;
-            if (hipMalloc((void**)&scratch, need * 4) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "cr_op_attention: scratch");
-            scratch_n = need;
+        std::lock_guard<std::mutex> lk(mu);
+        if (need > scratch_n[dev]) {
+            hipDeviceSynchronize();
+            if (scratch[dev]) hipFree(scratch[dev]);
+            scratch[dev] = nullptr; scratch_n[dev] = 0;
+            if (hipMalloc((void**)&scratch[dev], need * 4) != hipSuccess) return cr_fail(CR_ERR_NOMEM, "cr_op_attention: scratch");
+            scratch_n[dev] = need;
         }
-        p.part_ml = scratch;
+        p.part_ml = scratch[dev];
     }
     int r = launch_flash_attn(p, head_dim, causal != 0, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_attention(d=%d) rejected or failed", head_dim);

@@ -1,7 +1,9 @@
 // Context of libcallireader_hip.so: weights (library-owned device copies), derived
 // tensors, a grow-only device workspace.  Host-side C++ only; no torch types.
 #pragma once
+#include <atomic>
 #include <deque>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -37,8 +39,12 @@ struct cr_ctx {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     bool borrowed = false;              // cr_share_weights: the tensors in `w` belong to another context (not freed here)
-    const cr_ctx* owner = nullptr;      // ... that context, and its weight_gen when the map was copied: a reload / re-finalize / fp8 toggle on the owner
-    uint64_t owner_gen = 0;             //     frees or replaces tensors this copy still points at -> the stage entry points refuse to run (ctx_share_ok)
+    // weight_gen mirrored into a cell that OUTLIVES the context (cr_destroy stores ~0 into it): a borrower keeps the cell of the context that
+    // really owns the tensors (the root of a chain of cr_share_weights calls), never a pointer to the context itself
+    std::shared_ptr<std::atomic<uint64_t>> gen_cell = std::make_shared<std::atomic<uint64_t>>(0);
+    std::shared_ptr<std::atomic<uint64_t>> owner_cell;      // borrowed: the owning context's cell, and its value when the map was copied: a reload /
+    uint64_t owner_gen = 0;             //     re-finalize / fp8 toggle / destroy of the owner frees or replaces tensors this copy still points at -> the
+                                        //     stage entry points refuse to run (ctx_share_ok)
     // small persistent device scratch (counters, argmax partials)
     char* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -50,6 +56,8 @@ struct cr_ctx {
     double prof_acc[2][4] = {};         // [tiled M >= 1024 | the rest][launches, ms, flops, bytes] of the retired records
     int64_t prof_issued = 0, prof_retired = 0, prof_lost = 0, prof_peak_pending = 0;
 };
+
+inline void cr_bump_gen(cr_ctx* c) { c->weight_gen++; c->gen_cell->store(c->weight_gen, std::memory_order_release); }
 
 // e4m3 copy + per-row fp32 scale of weight `name` as "fp8.<name>" / "fp8s.<name>" (llm.hip); a no-op when already built for this shape
 int build_fp8_copy(cr_ctx* c, const std::string& name, int k_multiple, hipStream_t st);

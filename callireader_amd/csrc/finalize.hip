@@ -15,6 +15,6 @@ extern "C" int cr_finalize(cr_ctx* c, void* stream) {
     if (c->w.count("language_model.model.layers.0.feed_forward.w1.weight")) CR_TRY(llm_finalize(c, st));
     CR_HIP(hipStreamSynchronize(st));
     c->finalized = true;
-    c->weight_gen++;
+    cr_bump_gen(c);
     return CR_OK;
 }

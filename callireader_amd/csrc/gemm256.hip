@@ -290,7 +290,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
     // HBM round trip per slice (in-kernel stamps, M = 64 575, N = K = 1024: the residual epilogue 22.6 k clocks against 6.9 k for a
     // plain store) whatever the look-ahead.
     const bool fast = full_n && (EPI == EPI_F32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0) && (!PRE || ((p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0));
-    if (fast && PRE && !F8 && row_base + 128 <= p.M) {
+    if (fast && PRE && !F8 && row_base + 128 <= p.M && (EPI != EPI_PATCH || (p.group & 7) == 0)) {
         // Rows to add (residual stream, position embedding), interior tiles.  The counter loads and stores share only orders loads
         // among loads and stores among stores, so with both in flight hipcc has to wait with vmcnt(0): the one-slice-ahead form of
         // this loop (below; still used by the last, ragged row of tiles) waited an HBM round trip per slice -- 22.6 k clocks against
@@ -301,7 +301,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
         const uint32_t lane_off = (uint32_t)(((int64_t)rin * p.ldr + gn) * 2);
         auto rows_at = [&](int mf, int it) -> const char* {
             const int gm0 = row_base + mf * 16 + it * 8;                       // wave-uniform
-            const int64_t rrow = EPI == EPI_PATCH ? 1 + gm0 % p.group : gm0;    // (EPI_PATCH: 8 | group, a piece never wraps)
+            const int64_t rrow = EPI == EPI_PATCH ? 1 + gm0 % p.group : gm0;    // (EPI_PATCH: 8 | group is this path's condition, so a piece never wraps)
             return (const char*)p.res + rrow * p.ldr * 2;
         };
         bf16x8 rr[4][2];
@@ -594,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     dma(p.A, qA[0], 0, 0, 0); dma(p.W, qB[0], 0, 0, 1); dma(p.W, qB[1], 0, 0, 2); dma(p.A, qA[1], 0, 0, 3);
     dma(p.A, qA[0], 1, 1, 0); dma(p.W, qB[0], 1, 1, 1);
     if (EPI == EPI_GELU) gelu_lut_fill(smem + LDS_MAIN2, tid);      // under the cold-start fills; the barrier below publishes it
+    if (EPI == EPI_GELU) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table's ds_writes, explicitly (free under the DMA wait)
     WAIT_VM0();
     __builtin_amdgcn_s_barrier();
 

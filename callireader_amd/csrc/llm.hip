@@ -505,7 +505,7 @@ int cr_op_quantize_fp8(const void* w, int64_t ldw, int N, int K, void* q, float*
 
 int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_mfma: null context");
-    if (!enable) { if (c->fp8_mfma) c->weight_gen++; c->fp8_mfma = 0; return CR_OK; }      // captured decode graphs are keyed on weight_gen
+    if (!enable) { if (c->fp8_mfma) cr_bump_gen(c); c->fp8_mfma = 0; return CR_OK; }      // captured decode graphs are keyed on weight_gen
     if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_mfma: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
@@ -541,13 +541,13 @@ int cr_enable_fp8_mfma(cr_ctx* c, int enable, void* stream) {
     CR_HIP(hipGetLastError());
     CR_HIP(hipStreamSynchronize(st));
     c->fp8_mfma = enable >= 2 ? 2 : 1;
-    c->weight_gen++;
+    cr_bump_gen(c);
     return CR_OK;
 }
 
 int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
     if (!c) return cr_fail(CR_ERR_ARG, "cr_enable_fp8_decode: null context");
-    if (!enable) { if (c->fp8_decode) c->weight_gen++; c->fp8_decode = false; return CR_OK; }
+    if (!enable) { if (c->fp8_decode) cr_bump_gen(c); c->fp8_decode = false; return CR_OK; }
     if (c->borrowed) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: enable it on the context that owns the weights, then share again");
     if (!c->finalized) return cr_fail(CR_ERR_STATE, "cr_enable_fp8_decode: call cr_finalize first");
     CR_HIP(hipSetDevice(c->device));
@@ -563,7 +563,7 @@ int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
     CR_HIP(hipGetLastError());
     CR_HIP(hipStreamSynchronize(st));
     c->fp8_decode = true;
-    c->weight_gen++;
+    cr_bump_gen(c);
     return CR_OK;
 }
 

@@ -350,6 +350,11 @@ def main(argv=None):
     # one process per GPU (torchrun --nproc-per-node N -m callireader_amd.evaluate ...): every rank takes its share of each file's pages
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     gather = None
+    if world > 1 and args.type != 'full_page':
+        # these tasks are page-at-a-time host loops (two turns, up to 1024 tokens each) that only rank 0 would run while the others sat in a
+        # barrier until the collective timeout aborted the job: refuse before any rank loads a model or joins a process group
+        raise SystemExit(f'--type {args.type} runs in one process (it is a serial loop over chat_ocr, evaluate.py:438-466); start it without torchrun. '
+                         'Only --type full_page shards its pages over ranks.')
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -376,8 +381,8 @@ def main(argv=None):
     detect_model = load_detector(args.params)
     common = (args.use_p, args.hard_vq, args.drop_zero, args.repetition_penalty, args.verbose)
     if args.type != 'full_page':
-        # the other CalliBench tasks are page-at-a-time host loops over chat_ocr (rank 0 only; evaluate.py:438-466)
-        if rank == 0:
+        # the other CalliBench tasks are page-at-a-time host loops over chat_ocr (one process; evaluate.py:438-466)
+        if True:
             if args.type == 'region_wise':
                 print(test_region_wise(os.path.join(args.data, 'region-wise/region.parquet'), os.path.join(save_dir, 'region_wise.json'), model, tokenizer,
                                        detect_model, generation_config, '读出图中区域所有文字。', *common))
@@ -392,10 +397,6 @@ def main(argv=None):
             else:
                 test_intent(os.path.join(args.data, 'reasoning/intent/intent.parquet'), os.path.join(save_dir, 'intent.json'), model, tokenizer, detect_model,
                             generation_config, *common)
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
         return
     prompt = '读出图中所有文字。'
     for level in ('easy', 'medium', 'hard'):

@@ -1,4 +1,6 @@
 """CalliAlign parity on a real MI355X: resampler, cosine VQ, de-normalisation vs the CPU oracle."""
+import math
+
 import pytest
 import torch
 
@@ -76,14 +78,33 @@ def test_vq_planted_and_random(setup):
     assert int(idx[0, 0]) == 123 and int(idx[1, 2]) == 5002 and int(idx[2, 1]) == 0
     # cosine of the planted rows is ~1 on both sides; elsewhere the max cosine must agree to bf16 resolution
     assert torch.allclose(cos, rcos.float(), atol=8e-3)
-    # random rows: near-ties between table rows are possible at bf16; accept an index whose cosine ties
-    # the oracle's maximum within one bf16 step of the similarity matrix
+    # Index work is exact work (round-3 verdict): an index may differ from the oracle's only at a MEASURED tie.  sim = the oracle's own
+    # bf16 similarity matrix (similarity.py:17-19).  Where the oracle's top-2 gap exceeds 2^-7 the indices must be equal outright; a
+    # differing index passes only if the oracle's gap between the two rows is at most ONE bf16 step of the similarity there AND the HIP
+    # GEMM's own similarities at those two rows (the tiled kernel on the same normalised operands) straddle it: HIP's pick >= the oracle's.
+    from callireader_amd import engine as E
     xn = torch.nn.functional.normalize(q, p=2, dim=2)
     tn = torch.nn.functional.normalize(table, p=2, dim=1)
     sim = torch.matmul(xn, tn.t()).float()
-    picked = sim.gather(2, idx.unsqueeze(-1)).squeeze(-1)
-    assert (sim.max(dim=2).values - picked <= 8e-3).all()
-    assert (idx == ridx).float().mean() >= 0.8
+    top2 = sim.topk(2, dim=2).values
+    flat_x = xn.reshape(-1, xn.shape[-1])
+    n_diff = 0
+    for b in range(idx.shape[0]):
+        for j in range(idx.shape[1]):
+            i_h, i_o = int(idx[b, j]), int(ridx[b, j])
+            if i_h == i_o:
+                continue
+            n_diff += 1
+            assert float(top2[b, j, 0] - top2[b, j, 1]) <= 2.0 ** -7, (b, j, 'the oracle has a clear maximum here')
+            v = float(sim[b, j, i_o])
+            gap = v - float(sim[b, j, i_h])
+            ulp = 2.0 ** (math.floor(math.log2(abs(v))) - 7) if v != 0 else 0.0
+            assert 0.0 <= gap <= ulp, (b, j, i_h, i_o, gap, ulp)
+            rows = torch.stack([tn[i_o], tn[i_h]] + [tn[(i_o + 1 + k) % tn.shape[0]] for k in range(14)])     # 16 table rows, the two candidates first
+            s_hip = E.op_gemm(0, flat_x[b * idx.shape[1] + j][None].expand(16, -1).contiguous().cuda(), rows.cuda(), kernel=1).float().cpu()[0]
+            print(f'  VQ ({b},{j}): HIP {i_h} vs oracle {i_o}: oracle gap {gap:.3e} (one step {ulp:.3e}); HIP similarities {float(s_hip[1]):.6f} / {float(s_hip[0]):.6f}')
+            assert float(s_hip[1]) >= float(s_hip[0]), (b, j, 'the HIP similarities do not straddle the oracle\'s gap')
+    print(f'VQ: {n_diff} of {idx.numel()} indices differ from the oracle, all at measured ties')
 
 
 def test_denorm_branches(setup):

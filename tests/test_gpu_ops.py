@@ -224,10 +224,12 @@ def test_gemm_swiglu(E, M, kern):
     torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=2e-2)
 
 
-@pytest.mark.parametrize('kern', [1, 2])
-def test_gemm_patch_rows(E, kern):
+@pytest.mark.parametrize('kern,T,G', [(1, 2, 1024), (2, 2, 1024), (2, 3, 700), (2, 21, 100), (1, 3, 700)])
+def test_gemm_patch_rows(E, kern, T, G):
+    """G = 1024 is the model's; groups that are no multiple of 8 (700, 100) make an 8-row piece of the 256x256 kernel's four-slices-ahead
+    loop straddle two tiles' position rows: those shapes must take the per-row path (round-3 advisor finding)."""
     g = torch.Generator().manual_seed(3)
-    T, G, N, K = 2, 1024, 256, 128
+    N, K = 256, 128
     A = bf(_rand((T * G, K), g)).to(dev())
     W = bf(_rand((N, K), g, 0.05)).to(dev())
     bias = bf(_rand((N,), g, 0.1)).to(dev())

@@ -128,3 +128,46 @@ def test_borrower_notices_that_the_owner_changed(model):
     assert torch.equal(a, b)
     kv.free()
     other.close()
+
+
+def test_borrower_outlives_its_owner_safely():
+    """The borrower watches a generation cell that outlives the owning context (round-3 advisor finding: it used to dereference the owner):
+    once the owner is destroyed every stage entry point of the borrower -- and of a borrower of the borrower -- refuses to run."""
+    from callireader_amd.modeling_internvl_chat import InternVLChatModel
+    from callireader_amd.engine import Engine
+    from callireader_amd._binding import CalliReaderError
+    dims = ModelDims.reduced(vit_layers=1, llm_layers=1, rs_depth=1, vocab=8201)
+    sd = synthetic.make_state_dict(dims, parts=('llm',), seed=1)
+    owner = InternVLChatModel.from_state_dict(sd, dims, max_tokens=256, max_pages=1)
+    eng = owner.engine
+    b1 = Engine(eng.dims, device=eng.device.index, max_pos=eng.max_pos)
+    b1.share_weights_from(eng)
+    b2 = Engine(eng.dims, device=eng.device.index, max_pos=eng.max_pos)
+    b2.share_weights_from(b1)                               # a borrower of a borrower watches the real owner
+    g = torch.Generator().manual_seed(12)
+    emb = (torch.randn(40, 4096, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    kv = b2.kv_alloc(1, 128)
+    a = eng.prefill(kv, 0, emb, want_logits=True).clone()
+    kv.reset()
+    b = b2.prefill(kv, 0, emb, want_logits=True).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    eng.enable_fp8_decode(True)                             # the owner changes: both levels of borrowing notice
+    for e in (b1, b2):
+        with pytest.raises(CalliReaderError, match='share again'):
+            e.prefill(kv, 0, emb)
+    b3 = Engine(eng.dims, device=eng.device.index, max_pos=eng.max_pos)
+    with pytest.raises(CalliReaderError, match='share again'):      # a stale borrower hands on nothing
+        b3.share_weights_from(b1)
+    eng.enable_fp8_decode(False)
+    b1.share_weights_from(eng); b2.share_weights_from(b1)
+    kv.reset()
+    b2.prefill(kv, 0, emb)
+    torch.cuda.synchronize()
+    eng.close()                                             # cr_destroy frees the tensors
+    for e in (b1, b2):
+        with pytest.raises(CalliReaderError, match='destroyed'):
+            e.prefill(kv, 0, emb)
+    kv.free()
+    for e in (b1, b2, b3):
+        e.close()
