@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "ctx.hpp"
+#include "decode.hpp"
 #include "misc.hpp"
 #include "norm.hpp"
 
@@ -137,6 +138,7 @@ int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     c->d = *desc;
     { const char* e = getenv("CR_NO_SLICED_DECODE"); c->no_sliced_decode = e && atoi(e) != 0; }
     { const char* e = getenv("CR_DECODE_GRAPH"); if (e) c->decode_graph = atoi(e) != 0; }
+    { const char* e = getenv("CR_DECODE_FUSED"); if (e) c->fused_decode = atoi(e) != 0; }
     c->scratch_bytes = 1 << 20;
     if (hipMalloc((void**)&c->scratch, c->scratch_bytes) != hipSuccess) { delete c; return cr_fail(CR_ERR_NOMEM, "scratch"); }
     hipMemset(c->scratch, 0, c->scratch_bytes);
@@ -281,6 +283,18 @@ int cr_op_rmsnorm(const void* in, void* out, const void* gamma, int64_t rows, in
     p.gamma = (const bf16*)gamma; p.rows = rows; p.eps = eps;
     int r = launch_rmsnorm(p, n, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_rmsnorm(rows=%lld, n=%d) rejected or failed", (long long)rows, n);
+    return CR_OK;
+}
+
+int cr_op_decode_gemm(int which, int flags, const void* W, int64_t ldw, int M, int N, int K, const void* X, int64_t ldx, const void* xres,
+                      const void* gamma, float eps, void* xio, void* C, int64_t ldc, const void* cosT, const void* sinT, void* q_out, void* kc,
+                      void* vc, const int32_t* seqs, const int32_t* lens, int max_tokens, void* stream) {
+    DecodeGemmParams p{};
+    p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.X = (const bf16*)X; p.ldx = ldx; p.xres = (const bf16*)xres;
+    p.gamma = (const bf16*)gamma; p.eps = eps; p.xio = (bf16*)xio; p.C = C; p.ldc = ldc; p.cosT = (const bf16*)cosT; p.sinT = (const bf16*)sinT;
+    p.q_out = (bf16*)q_out; p.kc = (bf16*)kc; p.vc = (bf16*)vc; p.seqs = seqs; p.lens = lens; p.max_tokens = max_tokens; p.flags = flags;
+    const int r = launch_decode_gemm(which, p, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_decode_gemm(which=%d, M=%d, N=%d, K=%d) rejected or failed to launch", which, M, N, K);
     return CR_OK;
 }
 

@@ -1,0 +1,27 @@
+// Small-batch decode GEMMs with their neighbours folded in (gemm_decode.hip)
+#pragma once
+#include "common.hpp"
+
+constexpr int DECODE_FUSED_MAX_ROWS = 4;     // beyond this the separate kernels are faster (gemm_decode.hip's header, profiles/round4/)
+
+enum DecodeGemm { DEC_WQKV = 0, DEC_WO = 1, DEC_W13 = 2, DEC_W2 = 3, DEC_HEAD = 4 };
+
+struct DecodeGemmParams {
+    const bf16* W; int64_t ldw;          // [N][K] as nn.Linear stores it (w1|w3: the interleaved derived tensor)
+    int M, N, K;
+    const bf16* X; int64_t ldx;          // DEC_WO / DEC_W2: activations [M][K]
+    const bf16* xres;                    // DEC_WQKV / DEC_W13 / DEC_HEAD: residual rows [M][4096] the prologue normalises
+    const bf16* gamma; float eps;        //   ... with this RMSNorm weight
+    bf16* xio;                           // DEC_WO / DEC_W2: residual rows [M][4096], updated in place
+    void* C; int64_t ldc;                // DEC_W13: bf16 [M][N / 2]; DEC_HEAD: float [M][N]
+    // DEC_WQKV: RoPE tables [max_pos][128], q rows [M][4096], this layer's K / V cache [n_seqs][8][max_tokens][128], cache slot and
+    // position (= tokens cached so far) of every row
+    const bf16 *cosT, *sinT;
+    bf16 *q_out, *kc, *vc;
+    const int32_t *seqs, *lens;
+    int max_tokens;
+    int flags;                           // reserved for tuning knobs (cr_op_decode_gemm / CR_DEC_FLAGS); none at present
+};
+
+bool decode_fused_supported(int M, int ff);
+int launch_decode_gemm(int which, const DecodeGemmParams& p, hipStream_t stream);

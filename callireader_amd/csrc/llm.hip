@@ -16,6 +16,7 @@
 
 #include "attention.hpp"
 #include "ctx.hpp"
+#include "decode.hpp"
 #include "misc.hpp"
 #include "norm.hpp"
 
@@ -341,6 +342,9 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
               s_2 = decode ? gemm_partial_splits(D, ff) : 0;
     const bool sliced = decode && M <= 64 && s_qkv > 0 && s_o > 0 && s_2 > 0 && !c->no_sliced_decode;
     float* pbuf = sliced ? ar.take<float>((size_t)std::max(s_qkv * QKV, std::max(s_o, s_2) * D) * M) : nullptr;
+    // small batches (<= 16 rows): gemm_decode.hip folds the norms, RoPE + split and the residual adds into the five GEMMs -- six launches
+    // per layer instead of nine, every sum in the order of the kernels below (a row's bits do not depend on its batch)
+    const bool fused = sliced && c->fused_decode && !c->fp8_decode && decode_fused_supported(M, ff);
     // cr_llm_hidden_probe (parity tooling): rows [row0, row0 + rows) of the residual stream before layer 0 and after every layer
     auto probe = [&](int slot) -> int {
         if (!c->probe_dst || decode || c->probe_row0 + c->probe_rows > M) return CR_OK;
@@ -355,6 +359,35 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         bf16* kc = kv->k + l * per_layer;
         bf16* vc = kv->v + l * per_layer;
         // prefill on the fp8 matrix-core path: both norms emit e4m3 rows + scales, wqkv and w1|w3 take them (gemm256 F8)
+        if (fused) {
+            DecodeGemmParams dp{};
+            dp.M = M; dp.eps = c->d.rms_eps;
+            dp.W = w.wqkv; dp.ldw = D; dp.N = QKV; dp.K = D; dp.xres = x; dp.gamma = w.an;
+            dp.cosT = cosT; dp.sinT = sinT; dp.q_out = q; dp.kc = kc; dp.vc = vc; dp.seqs = d_seqs; dp.lens = kv->d_len; dp.max_tokens = kv->max_tokens;
+            CR_TRY(launch_decode_gemm(DEC_WQKV, dp, st));
+            AttnParams ap{};
+            ap.K = kc; ap.V = vc; ap.Q = q; ap.O = ao;
+            ap.k_bs = ap.v_bs = (int64_t)NKV * kv->max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)kv->max_tokens * HD;
+            ap.q_prescale = 1.0f; ap.s_div = 11.313708498984761f;
+            ap.q_bs = D; ap.q_rs = HD; ap.q_hs = 4 * HD; ap.o_bs = D; ap.o_rs = HD; ap.o_hs = 4 * HD;
+            ap.B = M; ap.H = NKV; ap.Sq = NH / NKV; ap.Sk = 0; ap.kv_group = 1; ap.q_pos0 = 0;
+            ap.seq_map = d_seqs; ap.sk_arr = kv->d_len; ap.sk_add = 1;
+            ap.nsplit = nsplit; ap.part_ml = part; ap.part_o = part + (size_t)M * NKV * nsplit * (NH / NKV) * 2;
+            if (launch_flash_attn_split(ap, HD, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
+            DecodeGemmParams dq{};
+            dq.M = M; dq.eps = c->d.rms_eps;
+            dq.W = w.wo; dq.ldw = D; dq.N = D; dq.K = D; dq.X = ao; dq.ldx = D; dq.xio = x;
+            CR_TRY(launch_decode_gemm(DEC_WO, dq, st));
+            dq = DecodeGemmParams{};
+            dq.M = M; dq.eps = c->d.rms_eps;
+            dq.W = w.w13; dq.ldw = D; dq.N = 2 * ff; dq.K = D; dq.xres = x; dq.gamma = w.fn; dq.C = act; dq.ldc = ff;
+            CR_TRY(launch_decode_gemm(DEC_W13, dq, st));
+            dq = DecodeGemmParams{};
+            dq.M = M; dq.eps = c->d.rms_eps;
+            dq.W = w.w2; dq.ldw = ff; dq.N = D; dq.K = ff; dq.X = act; dq.ldx = ff; dq.xio = x;
+            CR_TRY(launch_decode_gemm(DEC_W2, dq, st));
+            continue;
+        }
         const bool m8 = any8 && w.q_qkv && w.s_qkv && w.q_13 && w.s_13;
         const bool m8all = m8 && c->fp8_mfma >= 2 && w.q_o && w.s_o && w.q_2 && w.s_2;      // level 2: wo and w2 as well (their inputs take a quantiser pass)
         if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st, m8 ? hs : nullptr));
@@ -760,10 +793,17 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
     auto enqueue_step = [&](hipStream_t st) -> int {
         hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, table, force_tokens, kv->d_seqs, kv->d_gen, kv->d_ngen, kv->gen_cap, x);
         CR_TRY(run_layers(c, kv, x, n, true, {}, nullptr, nullptr, kv->d_seqs, nsplit, st));
-        CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
         const DevTensor *q_out = opt(c, "fp8.language_model.output.weight"), *s_out = opt(c, "fp8s.language_model.output.weight");
+        const int ff_ = (int)WT(c, "derived.w13.0")->shape[0] / 2;
+        if (c->fused_decode && !c->fp8_decode && !c->no_sliced_decode && decode_fused_supported(n, ff_)) {
+            DecodeGemmParams dh{};                                // final RMSNorm folded into the LM head (gemm_decode.hip)
+            dh.M = n; dh.eps = c->d.rms_eps; dh.W = ow; dh.ldw = D; dh.N = V; dh.K = D; dh.xres = x; dh.gamma = nw; dh.C = lg; dh.ldc = V;
+            CR_TRY(launch_decode_gemm(DEC_HEAD, dh, st));
+        } else {
+        CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
         if (c->fp8_decode && n <= 64 && q_out && s_out) CR_TRY(gemm8(c, EPI_F32, hl, D, q_out, s_out, lg, V, nullptr, 0, n, V, D, st));
         else CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
+        }
         if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(pick_kernel, dim3(n), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, 0, kv->d_seqs, kv->d_gen, kv->d_ngen,
                            kv->d_len, kv->gen_cap, 1);

@@ -11,18 +11,6 @@
 
 namespace {
 
-__device__ __forceinline__ void load16(const bf16* p, float* x) {
-    bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + 8);
-#pragma unroll
-    for (int e = 0; e < 8; e++) { x[e] = bf2f(a[e]); x[8 + e] = bf2f(b[e]); }
-}
-__device__ __forceinline__ void store16(bf16* p, const float* y) {
-    bf16x8 a, b;
-#pragma unroll
-    for (int e = 0; e < 8; e++) { a[e] = f2bf(y[e]); b[e] = f2bf(y[8 + e]); }
-    *(bf16x8*)p = a; *(bf16x8*)(p + 8) = b;
-}
-
 // TPR threads per row (N = 16 * TPR); 256-thread workgroup holds 256/TPR rows.
 template <int TPR>
 __device__ __forceinline__ float row_sum(float v, float* red, int tid) {
@@ -114,17 +102,9 @@ __global__ __launch_bounds__(256) void rmsnorm4096_kernel(const NormParams p) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
-    float x[16];
+    float x[16], y[16];
     load16(p.in + row * p.ld_in + tid * 16, x);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; e++) s += x[e] * x[e];
-    const float var = row_sum<256>(s, red, tid) * (1.0f / 4096.0f);
-    const float rs = rsqrtf(var + p.eps);
-    float g[16], y[16];
-    load16(p.gamma + tid * 16, g);
-#pragma unroll
-    for (int e = 0; e < 16; e++) y[e] = g[e] * rbf(x[e] * rs);
+    rmsnorm_row16(x, p.gamma + tid * 16, p.eps, red, tid, y);
     if (p.out8) store_row_e4m3<256>(p, row, tid, y, red, tid, true);
     else store16(p.out + row * p.ld_out + tid * 16, y);
 }
@@ -154,15 +134,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm4096_kernel(bf16* __restrict__
     for (int e = 0; e < 16; e++) x[e] = rbf(x[e] + rbf(a[e]));
     store16(xio + row * 4096 + tid * 16, x);
     if (!gamma) return;
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; e++) ss += x[e] * x[e];
-    const float var = row_sum<256>(ss, red, tid) * (1.0f / 4096.0f);
-    const float rs = rsqrtf(var + eps);
-    float g[16], y[16];
-    load16(gamma + tid * 16, g);
-#pragma unroll
-    for (int e = 0; e < 16; e++) y[e] = g[e] * rbf(x[e] * rs);
+    float y[16];
+    rmsnorm_row16(x, gamma + tid * 16, eps, red, tid, y);
     store16(out + row * 4096 + tid * 16, y);
 }
 

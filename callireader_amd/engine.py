@@ -271,7 +271,7 @@ class KVCache:
 
 
 # ---- single operators (tests / profiling) ----
-def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None, kernel=0):
+def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None, kernel=0, out=None):
     """kernel: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent, 3 weight-streaming (tests pin one)."""
     M, K = A.shape
     N = Wt.shape[0]
@@ -281,7 +281,7 @@ def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torc
         mrows, out_dtype = 8 * M, torch.float32
     if epi == 8:                     # cosine-VQ partials: per row and 64-column block {column (low word), bits of the bf16 max (high word)}
         ncols, out_dtype = ((N + 63) // 64 + 1) & ~1, torch.int64
-    Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
+    Cc = out if out is not None else torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
     B.check(B.lib.cr_op_gemm(epi | (kernel << 8), _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')
     return Cc
@@ -365,3 +365,14 @@ def op_attention(q, k, v, o, strides, Bn, H, Sq, Sk, head_dim, kv_group=1, causa
     B.check(B.lib.cr_op_attention(_p(q), _p(k), _p(v), _p(o), st, Bn, H, Sq, Sk, head_dim, kv_group, 1 if causal else 0,
                                   q_pos0, q_prescale, s_div, _stream()), 'cr_op_attention')
     return o
+
+
+def op_decode_gemm(which, W, M, X=None, xres=None, gamma=None, eps=1e-5, xio=None, C_out=None, rope=None, flags=0):
+    """cr_op_decode_gemm: one small-batch decode GEMM with its neighbours folded in (gemm_decode.hip).  which: 0 wqkv (rope = dict with
+    cos, sin, q_out, kc, vc, seqs, lens, max_tokens), 1 wo, 2 w1|w3, 3 w2, 4 LM head."""
+    N, K = W.shape
+    r = rope or {}
+    B.check(B.lib.cr_op_decode_gemm(which, flags, _p(W), K, M, N, K, _p(X), X.shape[1] if X is not None else 0, _p(xres), _p(gamma), eps, _p(xio),
+                                    _p(C_out), C_out.shape[1] if C_out is not None else 0, _p(r.get('cos')), _p(r.get('sin')), _p(r.get('q_out')),
+                                    _p(r.get('kc')), _p(r.get('vc')), _p(r.get('seqs')), _p(r.get('lens')), r.get('max_tokens', 0), _stream()),
+            'cr_op_decode_gemm')

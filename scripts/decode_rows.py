@@ -18,10 +18,10 @@ def child():
     dims = ModelDims.full()
     S = bench.PAGE_TILES * 256 + bench.CHAR_TILES * 3 + bench.TEXT_TOKENS
     P = max(ROWS)
-    model = InternVLChatModel.from_synthetic(dims, seed=0, device=0, max_tokens=S + 1024, max_pages=P)
+    model = InternVLChatModel.from_synthetic(dims, seed=0, device=0, max_tokens=S + 2048, max_pages=P)
     eng = model.engine
     g = torch.Generator(device='cuda').manual_seed(1)
-    kv = eng.kv_alloc(P, S + 1024)
+    kv = eng.kv_alloc(P, S + 2048)
     kv.reset()
     for i0 in range(0, P, 16):
         idx = list(range(i0, min(P, i0 + 16)))
@@ -39,19 +39,20 @@ def child():
             ts.append((time.perf_counter() - t0) / STEPS * 1e3)
         res[n] = min(ts)
         ctx = kv.length(0) if hasattr(kv, 'length') else -1
-        print(f'rows {n:3d}: {min(ts):.3f} ms per step (runs {", ".join(f"{t:.3f}" for t in ts)}), graph {os.environ.get("CR_DECODE_GRAPH", "0")}', flush=True)
+        print(f'rows {n:3d}: {min(ts):.3f} ms per step (runs {", ".join(f"{t:.3f}" for t in ts)}), graph {os.environ.get("CR_DECODE_GRAPH", "0")} fused {os.environ.get("CR_DECODE_FUSED", "1")}', flush=True)
     print('RESULT ' + json.dumps(res), flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     child()
 else:
     out = {}
-    for graph in ('0', '1'):
-        env = dict(os.environ, CR_DECODE_GRAPH=graph)
+    for name, graph, fused in (('separate kernels (CR_DECODE_FUSED=0), plain launches', '0', '0'), ('fused small-batch path, plain launches', '0', '1'),
+                               ('fused small-batch path, hipGraph replay', '1', '1')):
+        env = dict(os.environ, CR_DECODE_GRAPH=graph, CR_DECODE_FUSED=fused)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=env, capture_output=True, text=True)
         sys.stdout.write(p.stdout); sys.stderr.write(p.stderr[-2000:])
         for line in p.stdout.splitlines():
-            if line.startswith('RESULT '): out['graph' if graph == '1' else 'plain'] = json.loads(line[7:])
+            if line.startswith('RESULT '): out[name] = json.loads(line[7:])
     os.makedirs('gpurun_out', exist_ok=True)
     json.dump(out, open('gpurun_out/decode_rows.json', 'w'), indent=1)
     print(json.dumps(out))

@@ -150,6 +150,42 @@ def test_batched_decode_equals_single(setup):
     kv.free()
 
 
+@pytest.mark.parametrize('rows', [1, 2, 3, 4, 5])
+def test_fused_small_batch_decode_gives_the_separate_kernels_bits(setup, rows):
+    """Batches of <= 4 rows decode through gemm_decode.hip (RMSNorm prologues, RoPE + cache-write epilogue, residual-add epilogues: six
+    launches per layer); CR_DECODE_FUSED=0 keeps the separate kernels.  Logits, cache rows and ids must be the SAME BITS, step after step:
+    a row's result may not depend on which path its batch size selects (a 5-row batch takes the separate kernels in both engines)."""
+    import os
+    from callireader_amd.engine import Engine
+    eng = setup['eng']
+    os.environ['CR_DECODE_FUSED'] = '0'
+    try:
+        ref = Engine(setup['dims'], max_pos=2048)
+    finally:
+        del os.environ['CR_DECODE_FUSED']
+    ref.share_weights_from(eng)
+    lens = [300, 77, 130, 17, 64, 255, 256, 31, 129, 40, 200, 90, 5, 150, 33, 61][:rows]
+    embs = [prompt(S, 500 + i) for i, S in enumerate(lens)]
+    kva, kvb = eng.kv_alloc(rows + 1, 512), ref.kv_alloc(rows + 1, 512)
+    for i, e in enumerate(embs):
+        eng.prefill(kva, i + 1, e.cuda())
+        ref.prefill(kvb, i + 1, e.cuda())
+    order = list(range(rows, 0, -1))                                  # slot 0 stays empty, rows in reverse order
+    for step in range(5):
+        la = eng.decode(kva, order, penalty=1.3, want_logits=True).clone()
+        lb = ref.decode(kvb, order, penalty=1.3, want_logits=True).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb), (rows, step, float((la - lb).abs().max()))
+    for i in range(rows):
+        assert kva.generated(i + 1) == kvb.generated(i + 1)
+        pos = lens[i] + 3
+        for layer in (0, 1):
+            for which in (0, 1):
+                assert torch.equal(kva.read(layer, i + 1, pos, which), kvb.read(layer, i + 1, pos, which)), (i, layer, which)
+    kva.free(); kvb.free()
+    ref.close()
+
+
 def test_decode_graph_replay_equals_plain_launches(setup):
     """CR_DECODE_GRAPH=1 (opt-in): the decode step captured as a hipGraph and replayed -- across a change of the number
     of attention splits (a second capture) and with prefills in between -- generates exactly the plain path's ids."""
