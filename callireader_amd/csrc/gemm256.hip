@@ -75,6 +75,11 @@ constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per 
 #define WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
 #define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#ifdef CR_KO_STORE      // diagnostic build: the plain-store epilogue keeps its values alive but sends nothing (wrong results)
+#define CR_STORE_OUT(v, ptr) asm volatile("" ::"v"(v), "v"(ptr))
+#else
+#define CR_STORE_OUT(v, ptr) __builtin_nontemporal_store(v, ptr)
+#endif
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)   /* lgkmcnt(0); the builtin (unlike inline asm) is seen by the compiler's own wait insertion */
 
 // ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------------------------
@@ -383,7 +388,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
                     for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(rring[mf % (RPF + 1)][it][e]) + bf2f(v[e]));
                     if (gm < p.M) __builtin_nontemporal_store(o, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 } else {
-                    if (gm < p.M) __builtin_nontemporal_store(v, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
+                    if (gm < p.M) CR_STORE_OUT(v, (bf16x8*)((bf16*)p.C + orow * p.ldc + gn));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -474,7 +479,7 @@ __device__ __forceinline__ i32x8 f8_put(const i32x8& v, int ks, const bf16x8& fr
 // of 128 bytes per row is 128 k instead of 64, and a matrix slot issues 8 v_mfma_scale_f32_16x16x128_f8f6f4 (unit block
 // scales, 32 cycles each) where the bf16 kernel issues 16 v_mfma_f32_16x16x32_bf16 (16 cycles each): the same slot length at
 // twice the k.  The per-row / per-column fp32 scales are applied to the finished sum in the epilogue.
-template <int EPI, bool F8 = false>
+template <int EPI, bool F8 = false, bool BIG = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -562,6 +567,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // a phase = a memory slot (fragment reads of this phase, one unit's two DMA pieces, the counted wait) and a
     // matrix slot (16 MFMAs), each closed by s_barrier.  Waves 4..7 run one slot behind waves 0..3, so on every
     // SIMD one wave's matrix slot runs beside its partner's memory slot.
+#define MEM_SLOT_B(READS, DMA, WAIT)      /* 32-MFMA schedule: the reads are retired in front of the slot's barrier */ \
+    READS;                                                                                      \
+    DMA;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (WAIT) WAIT_VM8();                                                                       \
+    WAIT_LGKM0();                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    __builtin_amdgcn_s_barrier();
 #define MEM_SLOT(READS, DMA, WAIT)                                                              \
     READS;                                                                                      \
     DMA;                                                                                        \
@@ -584,6 +597,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(0);                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_barrier();
+#define MFMA_QUAD(mh, nh)                                                                       \
+    if (F8) {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) \
+            acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(  \
+                rb8[nh][j], ra8[i], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0, 0, 0, 0); \
+    } else {                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int i = 0; i < 4; i++) \
+            _Pragma("unroll") for (int j = 0; j < 2; j++)                                       \
+                acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[nh][j][ks], ra[i][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
+    }
+#define MFMA_SLOT2(mh0, nh0, mh1, nh1)                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                              \
+    MFMA_QUAD(mh0, nh0)                                                                         \
+    MFMA_QUAD(mh1, nh1)                                                                         \
+    __builtin_amdgcn_s_setprio(0);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    __builtin_amdgcn_s_barrier();
 
     int t_cur = blockIdx.x;
     if (t_cur >= ntiles) return;
@@ -593,6 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // ---- cold start (first tile of this workgroup only): K-tile 0 and U0, U1 of K-tile 1 issued, U0/U1 of K-tile 0 landed
     dma(p.A, qA[0], 0, 0, 0); dma(p.W, qB[0], 0, 0, 1); dma(p.W, qB[1], 0, 0, 2); dma(p.A, qA[1], 0, 0, 3);
     dma(p.A, qA[0], 1, 1, 0); dma(p.W, qB[0], 1, 1, 1);
+    if (BIG) dma(p.W, qB[1], 1, 1, 2);                         // (32-MFMA slots: phase 1 of the first pair stages U3 of K-tile 1)
     if (EPI == EPI_GELU) gelu_lut_fill(smem + LDS_MAIN2, tid);      // under the cold-start fills; the barrier below publishes it
     if (EPI == EPI_GELU) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table's ds_writes, explicitly (free under the DMA wait)
     WAIT_VM0();
@@ -614,11 +646,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const bool has_next = t_next < ntiles;
 #ifdef CR_DIAG_STAMPS
         uint64_t* dbg = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + (t_cur / gridDim.x)) * 4;
-        const bool stamp = p.scale && (wave & 3) == 0 && lane == 0 && (t_cur / gridDim.x) < 32;
+        const bool stamp = p.scale && (wave & 3) == 0 && lane == 0 && (t_cur / gridDim.x) < 31;      // row 31 holds the workgroup's real-time stamps
         if (stamp) dbg[0] = __builtin_amdgcn_s_memtime();
+        if (stamp && t_cur == (int)blockIdx.x) { uint64_t* d31 = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + 31) * 4; d31[0] = __builtin_amdgcn_s_memrealtime(); d31[2] = __builtin_amdgcn_s_memtime(); }
 #endif
         if (wm) __builtin_amdgcn_s_barrier();                  // waves 4..7 start one slot late
 
+        if (BIG) {
+        // Round 4: 32-MFMA matrix slots (template parameter BIG; launch_t picks it where it measured faster: N >= 2048 and K <= 8192).  A K-tile is TWO phases -- (0,0)+(0,1) on the A rows of mh = 0, then (1,1)+(1,0) on mh = 1 (the B
+        // fragments of both nh stay in registers: the same 64 fragment registers as before) -- so a K-tile costs four barrier-closed slots
+        // instead of eight; every slot carried ~45-50 clocks that were neither MFMA issue nor overlapped (in-kernel stamps: 594-623 clocks per
+        // 512 of MFMA issue).  The fragment reads are now retired (lgkmcnt(0)) at the END of the memory slot, in front of its barrier: a unit
+        // may then be re-staged in the very next slot (both groups' reads of it have been retired before the barrier that slot starts
+        // behind), which keeps every stage -> read distance at three phases = six slots:
+        //   phase   reads                         MFMAs           DMA (instructions per wave)
+        //     1     even U0 U1 U2 (16)            (0,0) (0,1)     odd  U3 of K-tile 2i+1           (2)
+        //     2     even U3 (8)                   (1,1) (1,0)     even U0 U1 U2 of K-tile 2i+2     (6)
+        //     3     odd  U0 U1 U2 (16)            (0,0) (0,1)     even U3 of K-tile 2i+2           (2)
+        //     4     odd  U3 (8)                   (1,1) (1,0)     odd  U0 U1 U2 of K-tile 2i+3     (6)
+        //   RAW: what phase p reads was staged in phase p - 3; vmcnt(8) at the end of every memory slot leaves the two most recent phases'
+        //   instructions (2 + 6) in flight, so it has landed in every wave before the barrier in front of the reads (late group: one slot later,
+        //   early group reads one slot after that).  WAR: above.  The look-ahead through a tile boundary is phases 2..4 of the last pair + phase 1
+        //   of the next tile's first pair.
+        for (int kt = 0; kt < nk; kt += 2) {
+            int k2 = kt + 2;
+            const bool wt = kt != 0;                           // first pair of a tile: phases 1-3 read what the drain before the epilogue retired
+            MEM_SLOT_B(READ_B(0, 1, 0); READ_B(0, 2, 1); READ_A(0, 0), dma(p.A, qA[1], kt + 1, 1, 3), wt);
+            MFMA_SLOT2(0, 0, 0, 1);
+            if (k2 >= nk) {                                    // last pair: the look-ahead belongs to the next tile
+                if (has_next) { int nm0, nn0; tile_origin(t_next, nm0, nn0); make_ptrs(nm0, nn0); k2 = 0; }
+                else k2 = nk - 2;                              // nothing follows: re-load dead units with the bytes they hold
+            }
+            MEM_SLOT_B(READ_A(0, 3), dma(p.A, qA[0], k2, 0, 0); dma(p.W, qB[0], k2, 0, 1); dma(p.W, qB[1], k2, 0, 2), wt);
+            MFMA_SLOT2(1, 1, 1, 0);
+            MEM_SLOT_B(READ_B(1, 1, 0); READ_B(1, 2, 1); READ_A(1, 0), dma(p.A, qA[1], k2, 0, 3), true);
+            MFMA_SLOT2(0, 0, 0, 1);
+            MEM_SLOT_B(READ_A(1, 3), dma(p.A, qA[0], k2 + 1, 1, 0); dma(p.W, qB[0], k2 + 1, 1, 1); dma(p.W, qB[1], k2 + 1, 1, 2), true);
+            MFMA_SLOT2(1, 1, 1, 0);
+        }
+        } else {
         for (int kt = 0; kt < nk; kt += 2) {
             int k2 = kt + 2;                                   // K-tile staged by phases 3..6 (and k2 + 1 by 7, 8, 1', 2')
             // first pair of a tile: everything phases 1..5 read landed before the epilogue of the previous tile (its
@@ -646,6 +712,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             MEM_SLOT(, dma(p.W, qB[0], k2 + 1, 1, 1), true);
             MFMA_SLOT(1, 0);
         }
+        }
 #ifdef CR_DIAG_STAMPS
         if (stamp) dbg[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -656,10 +723,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #endif       // the look-ahead (K-tile 0 and U0, U1 of K-tile 1 of the next tile) has landed: slots 1..4 rely on it
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----
+#ifdef CR_KO_EPI         // diagnostic build: no epilogue at all (wrong results): what hiding it completely could buy
+        _Pragma("unroll") for (int i = 0; i < 8; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
+#else
         if (EPI == EPI_GELU_Q8) epilogue_gelu_q8(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
         else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane, lut);
+#endif
 #ifdef CR_DIAG_STAMPS
         if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();
+        if (stamp && !has_next) { uint64_t* d31 = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + 31) * 4; d31[1] = __builtin_amdgcn_s_memrealtime(); d31[3] = __builtin_amdgcn_s_memtime(); }
 #endif
         if (!has_next) break;
         t_cur = t_next;
@@ -668,14 +740,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     WAIT_VM0();       // dead re-loads of the final pair must land before the workgroup releases its LDS
 }
 
-template <int EPI, bool F8 = false>
-int launch_t(const GemmParams& p, hipStream_t stream) {
+template <int EPI, bool F8, bool BIG>
+int launch_s(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
     static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)gemm256_kernel<EPI, F8>, LDS_BYTES2)) return CR_ERR_HIP;
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm256_kernel<EPI, F8, BIG>, LDS_BYTES2)) return CR_ERR_HIP;
     const int n_cu = cr_device_cus();
-    hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, F8, BIG>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), LDS_BYTES2, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+// Two schedules of the same sums (bit-identical results): 32-MFMA matrix slots measured 2-5 % faster on the wide outputs at K <= 4096 (ViT QKV
+// and fc1, prefill w1|w3, 8192^3), 16-MFMA slots 1-2 % faster on N = 1024 (proj, fc2) and on K = 14336 (w2): profiles/round4/.  CR_GEMM_SLOTS = 16 | 32
+// pins one (A/B aid).  The e4m3 instance keeps the 16-slot schedule (its registers are full).
+template <int EPI, bool F8 = false>
+int launch_t(const GemmParams& p, hipStream_t stream) {
+    static const int pin = [] { const char* e = getenv("CR_GEMM_SLOTS"); return e ? atoi(e) : 0; }();
+    const bool big = !F8 && (pin == 32 || (pin != 16 && p.N >= 2048 && p.K <= 8192));
+    if constexpr (!F8) { if (big) return launch_s<EPI, false, true>(p, stream); }
+    return launch_s<EPI, F8, false>(p, stream);
 }
 
 }  // namespace
