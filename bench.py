@@ -510,8 +510,9 @@ def main():
                                 'decode_remaining_tokens': round(max(per_step - vis_s - pre_s, 0.0) * 1e3, 1),
                                 'how': 'MAX over ranks of one extra stamped pass that stops after the first token; decode = timed step - those two'},
                   'all_gather': g2,
-                  'n1_denominator': f'the N = 1 default line IS this configuration at one GPU when --pages = --total-pages ({args.pages} vs {ws["n_pages"]}): '
-                                    'speed-up = this value / that value; no speed-up is printed here because this run did not measure N = 1'}
+                  'n1_denominator': ((f'the N = 1 line of `python bench.py --gpus 1 --pages {ws["n_pages"]}` is this configuration on one GPU'
+                                      + (' (= the default N = 1 line)' if ws['n_pages'] == 64 and args.pages == 64 else '')
+                                      + ': speed-up = this value / that value; none is printed here because this run did not measure N = 1'))}
         del ins
 
     result = None

@@ -195,7 +195,7 @@ __device__ __forceinline__ bf16x8 read_chunk(const char* buf, int r, int c) {
 
 template <int EPI, bool F8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[8][4], char* stg, int row_base, int col0,
-                                              int lane, const char* lut = nullptr) {
+                                              int lane, const char* lut = nullptr, const char* pre = nullptr) {
     constexpr bool ADD_ROWS = (EPI == EPI_LS_RES || EPI == EPI_RES);
     const bool has_bias = p.bias != nullptr;
     const bool full_n = col0 + 64 <= p.N;
@@ -210,7 +210,23 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
         }
     }
     auto dq_row = [&](int mf) { return F8 ? p.ascale[min(row_base + mf * 16 + (lane & 15), p.M - 1)] : 1.0f; };
-    {
+    if (pre) {
+        // bias (bytes 0..127) and LayerScale (128..255) of this wave's 64 columns were brought into its staging area by ONE LDS-DMA instruction at
+        // the tile's start (the kernel): loading them here cost every tile a global round trip with the matrix pipe idle -- QKV + bias 0.340 ms
+        // against 0.306 without a bias vector at M = 64 575
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int o = (j * 16 + (lane >> 4) * 4) * 2;
+            const bf16x4 b = *(const bf16x4*)(pre + o);
+#pragma unroll
+            for (int e = 0; e < 4; e++) bias_f[j][e] = has_bias ? bf2f(b[e]) : -0.0f;
+            if (EPI == EPI_LS_RES) {
+                const bf16x4 sc = *(const bf16x4*)(pre + 128 + o);
+#pragma unroll
+                for (int e = 0; e < 4; e++) scale_f[j][e] = bf2f(sc[e]);
+            }
+        }
+    } else {
         const bool vec = full_n && ((((uintptr_t)p.bias) | ((uintptr_t)p.scale)) & 7) == 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -644,6 +660,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int t_next = t_cur + gridDim.x;
         const bool has_next = t_next < ntiles;
+        // per-column epilogue operands of this wave's 64 columns -> its staging area, one LDS-DMA instruction (lanes 0..31: bias, 32..63: LayerScale),
+        // issued here so that it is the OLDEST vector-memory operation of the tile: the counted waits of the slots below leave the youngest in flight
+        // (16-slot instances only: in the 32-slot ones it measured 2-3 % slower -- nine more spilled registers around the tile boundary)
+        const bool pre_ok = !BIG && !F8 && EPI != EPI_ARGMAX && EPI != EPI_SWIGLU && (p.N & 63) == 0 && (p.bias || EPI == EPI_LS_RES) &&
+                            ((((uintptr_t)p.bias) | ((uintptr_t)(EPI == EPI_LS_RES ? p.scale : nullptr))) & 3) == 0;
+        if (pre_ok) {
+            const bf16* src = (lane < 32 || EPI != EPI_LS_RES) ? (p.bias ? p.bias : p.scale) : p.scale;
+            __builtin_amdgcn_global_load_lds(CR_GLB(src + n0 + wn * 64 + (lane & 31) * 2), CR_LDS(stg), 4, 0, 0);
+        }
 #ifdef CR_DIAG_STAMPS
         uint64_t* dbg = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + (t_cur / gridDim.x)) * 4;
         const bool stamp = p.scale && (wave & 3) == 0 && lane == 0 && (t_cur / gridDim.x) < 31;      // row 31 holds the workgroup's real-time stamps
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         _Pragma("unroll") for (int i = 0; i < 8; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
 #else
         if (EPI == EPI_GELU_Q8) epilogue_gelu_q8(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
-        else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane, lut);
+        else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane, lut, pre_ok ? stg : nullptr);
 #endif
 #ifdef CR_DIAG_STAMPS
         if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();

@@ -22,6 +22,8 @@ g = torch.Generator(device='cuda').manual_seed(0)
 _p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for (M, N, K, epi) in shapes:
+    nobias = epi >= 100                      # epi + 100: the same epilogue without a bias vector
+    epi %= 100
     A = (torch.rand(M, K, device='cuda', generator=g) * 2 - 1).bfloat16()
     W = ((torch.rand(N, K, device='cuda', generator=g) * 2 - 1) * 0.05).bfloat16()
     bias = (torch.rand(N, device='cuda', generator=g) * 0.1).bfloat16()
@@ -29,7 +31,7 @@ for (M, N, K, epi) in shapes:
     res = torch.rand(M, N if epi != 4 else N // 2, device='cuda', generator=g).bfloat16() if epi in (2, 3) else None
     Cc = torch.zeros(M, N // 2 if epi == 4 else N, device='cuda', dtype=torch.bfloat16)
     def run(fn):
-        rc = fn(epi | (2 << 8), _p(A), K, _p(W), K, _p(Cc), Cc.stride(0), _p(bias), _p(scale) if epi == 2 else _p(None), _p(res), res.stride(0) if res is not None else 0, M, N, K, 0, st())
+        rc = fn(epi | (2 << 8), _p(A), K, _p(W), K, _p(Cc), Cc.stride(0), _p(None if nobias else bias), _p(scale) if epi == 2 else _p(None), _p(res), res.stride(0) if res is not None else 0, M, N, K, 0, st())
         assert rc == 0, rc
     n = 10 if 2.0 * M * N * K < 2e12 else 3
     t = {name: [] for name, _ in libs}
@@ -43,7 +45,7 @@ for (M, N, K, epi) in shapes:
             for _ in range(n): run(fn)
             ev[1].record(); torch.cuda.synchronize()
             t[name].append(ev[0].elapsed_time(ev[1]) / n)
-    line = f'M={M} N={N} K={K} epi={epi}:'
+    line = f'M={M} N={N} K={K} epi={epi}{" (no bias)" if nobias else ""}:'
     for name, _ in libs:
         v = sorted(t[name])
         line += f'  {name} {v[len(v) // 2]:.4f} ms (min {v[0]:.4f}, {2.0 * M * N * K / v[len(v) // 2] / 1e9:.0f} TF)'

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from callireader_amd import engine as E
 
 GEMMS = [(64575, 3072, 1024, 'ViT QKV'), (64575, 1024, 1024, 'ViT proj'), (64575, 4096, 1024, 'ViT fc1'), (64575, 1024, 4096, 'ViT fc2'),
-         (25312, 28672, 4096, 'prefill w1|w3'), (25312, 4096, 14336, 'prefill w2')]
+         (25312, 28672, 4096, 'prefill w1|w3'), (25312, 4096, 14336, 'prefill w2'), (4096, 4096, 4096, '4096^3'), (8192, 8192, 8192, '8192^3')]
 ROUNDS = 5
 g = torch.Generator(device='cuda').manual_seed(0)
 
@@ -34,7 +34,8 @@ for (M, N, K, what) in GEMMS:
     W = (torch.rand(N, K, device='cuda', generator=g) * 2 - 1).bfloat16()
     Wt = W.t()
     C = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-    ours = lambda: E.op_gemm(0, A, W)
+    Co = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)      # both sides write into a preallocated output (op_gemm would otherwise zero-fill a new one per call)
+    ours = lambda: E.op_gemm(0, A, W, out=Co)
     vend = lambda: torch.matmul(A, Wt, out=C)
     ours(); vend(); torch.cuda.synchronize()
     n = 10 if M * N * K < 2e12 else 4
@@ -50,7 +51,7 @@ for (M, N, K, what) in GEMMS:
     rec['ours_rel_l2_vs_fp32'] = float((got - ref).norm() / ref.norm())
     out['gemm'].append(rec)
     print(f"{what:14s} M={M} N={N} K={K}: ours {rec['ours_ms']:.3f} ms {rec['ours_tflops']:.0f} TF | torch.matmul {rec['vendor_ms']:.3f} ms {rec['vendor_tflops']:.0f} TF | vendor/ours {rec['vendor_over_ours']:.3f}", flush=True)
-    del A, W, C
+    del A, W, C, Co
 
 def sdpa_backends():
     from torch.nn.attention import SDPBackend
