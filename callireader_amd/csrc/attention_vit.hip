@@ -194,6 +194,11 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         // l & 31: k ranges 0 and 2 of column c belong to query c, ranges 1 and 3 to query c + 16 -- so row 0 of `sel` is 1 on ranges
         // 0, 2 and row 1 on ranges 1, 3, and D[0][c] / D[1][c] (lanes 0..15, registers 0 / 1) accumulate the sums of queries c / c + 16.
         // 36 v_add_f32 per tile become four MFMAs of 16 cycles: the vector pipe is the busy one here (77 % against the matrix pipe's 42).
+        // Numerics (round-3 advisor note): the denominator is therefore the sum of the bf16-ROUNDED probabilities -- the same values the numerator
+        // P.V multiplies by, so the quotient is a weighted mean of V rows whose weights sum to exactly 1 (the reference, and the exact re-sweep /
+        // the CLS-query partials / attention.hip, sum the fp32 exponentials before rounding: their weights sum to 1 +- 2^-9).  A flagged block is
+        // redone AS A WHOLE by the exact kernel, never mixed; both forms sit inside the tests' bound (test_attention_vit_shape: 2 bf16 ulp of
+        // the fp32 reference; scripts/attn_bench.py: largest difference between the two kernels 0.0039 on unit-variance data).
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const u32x4_t pw = {pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]};
