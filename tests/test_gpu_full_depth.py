@@ -12,7 +12,7 @@ reference sits to exact arithmetic.
 Token bar: the HIP path's free-running greedy ids must equal the reference's.  A difference is only accepted at a step
 where the reference's own top-2 margin is below the measured logit difference bound (a tie the reference itself would
 resolve differently under any re-association), and then the test prints the step and that margin and walks on
-teacher-forced.  Everything measured is written to profiles/round3/full_depth_parity.json (gpurun_out/ on the GPU box
+teacher-forced.  Everything measured is written to profiles/round4/full_depth_parity.json (round 3's run: profiles/round3/) (gpurun_out/ on the GPU box
 as well) so the numbers quoted in DESIGN.md have an artifact.
 """
 import json
@@ -70,7 +70,7 @@ def check_near_tie(where, got, ref_id, hip_id, ref_logit_of, noise_abs):
 
 
 def _dump():
-    for d in (os.path.join(ROOT, 'profiles', 'round3'), os.path.join(ROOT, 'gpurun_out')):
+    for d in (os.path.join(ROOT, 'profiles', 'round4'), os.path.join(ROOT, 'gpurun_out')):
         try:
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, 'full_depth_parity.json'), 'w') as f:
@@ -222,7 +222,7 @@ def test_llm_layerwise_error_budget(gold, engine):
     """Where the logit difference comes from: the residual stream before layer 0 and after each of the 32 layers (three prompt
     rows), HIP against the reference's own hidden states (tests/golden/full_depth_layers.npz, scripts/make_golden_layers.py: forward
     hooks on the reference's decoder layers), next to the reference's OWN bf16-vs-fp32 distance at the same layer.  Written to
-    profiles/round3/full_depth_parity.json (key llm32_layers); bound: at every layer the HIP path sits no further from the bf16
+    profiles/round4/full_depth_parity.json (round 3's run: profiles/round3/) (key llm32_layers); bound: at every layer the HIP path sits no further from the bf16
     reference than the bf16 reference sits from its fp32 self."""
     g, meta = gold
     gl = np.load(os.path.join(ROOT, 'tests', 'golden', 'full_depth_layers.npz'))
@@ -373,7 +373,7 @@ def test_config1_example_page_end_to_end_vs_reference(gold, engine):
 
 def test_fp8_mfma_option_at_full_depth_is_recorded(gold, engine):
     """The fp8 matrix-core option (OFF by default) at full depth against the same reference vectors, both levels: recorded next to
-    the bf16 numbers in profiles/round3/full_depth_parity.json.  It is a THROUGHPUT option: e4m3 keeps 3 mantissa bits, every fp8 linear
+    the bf16 numbers in profiles/round4/full_depth_parity.json (round 3's run: profiles/round3/).  It is a THROUGHPUT option: e4m3 keeps 3 mantissa bits, every fp8 linear
     adds ~5 % of independent relative noise and on random-init weights 24 / 32 layers of it accumulate, so the numbers below are far
     outside the bf16 path's (and the greedy pick usually differs); what it costs on a real checkpoint is what
     `evaluate.py --compare_fp8` measures.  The assertions are sanity bounds only, and level 1 (norm-fed linears only) must sit closer

@@ -13,7 +13,7 @@ MaxLengthCriteria:
   B10  the B prompt with repetition_penalty 1.0 and max_new_tokens 40: loops, stops on the length.
 The reference's top-2 margin is >= 1.8 at every step, so there is NO near-tie escape here: the HIP path, through the drop-in
 `InternVLChatModel.generate_ocr`, must return exactly the reference's ids -- same length, same EOS.  The raw logits of every
-step are compared as well (top-16 of the reference).  Results: profiles/round3/peaked_streams.json.
+step are compared as well (top-16 of the reference).  Results: profiles/round4/peaked_streams.json (round 3's run: profiles/round3/).
 """
 import json
 import os
@@ -33,7 +33,7 @@ RESULTS = {}
 
 
 def _dump():
-    for d in (os.path.join(ROOT, 'profiles', 'round3'), os.path.join(ROOT, 'gpurun_out')):
+    for d in (os.path.join(ROOT, 'profiles', 'round4'), os.path.join(ROOT, 'gpurun_out')):
         try:
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, 'peaked_streams.json'), 'w') as f:
@@ -136,7 +136,7 @@ def test_free_running_logits_and_batched_decode(gold, model):
 def test_fp8_options_on_the_peaked_checkpoint_are_recorded(gold, model):
     """The fp8 switches are throughput options, OFF by default; this records what they do to a stream whose reference margins are wide
     (>= 2.6 at |logit| ~ 12): tokens of stream A equal to the reference's, first difference, per switch.  No equality is asserted -- the
-    record (profiles/round3/peaked_streams.json, key fp8) is the honest answer to "does fp8 keep the tokens on these weights"."""
+    record (profiles/round4/peaked_streams.json (round 3's run: profiles/round3/), key fp8) is the honest answer to "does fp8 keep the tokens on these weights"."""
     g, meta = gold
     ref_ids = g['A.ids'].tolist()
     eng = model.engine
