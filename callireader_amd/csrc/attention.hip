@@ -126,12 +126,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     {
         const bf16* qp = p.Q + q_base + (int64_t)qi_c * p.q_rs + (int64_t)head * p.q_hs + hh * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            qf[ks] = *(const bf16x8*)(qp + ks * 16);
-            if (p.q_prescale != 1.0f) {
+        for (int ks = 0; ks < KS; ks++) qf[ks] = *(const bf16x8*)(qp + ks * 16);      // all loads first: with the (run-time) prescale inside this loop hipcc
+        if (p.q_prescale != 1.0f) {                                                        // waited for every load in turn (KS dependent round trips per workgroup)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) qf[ks][e] = f2bf(bf2f(qf[ks][e]) * p.q_prescale);
-            }
         }
     }
 

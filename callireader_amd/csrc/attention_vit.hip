@@ -66,12 +66,12 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     auto load_q = [&](int row, bf16x8* dst) {
         const bf16* qp = Qb + (int64_t)row * p.q_rs + hh * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            dst[ks] = *(const bf16x8*)(qp + ks * 16);
-            if (p.q_prescale != 1.0f) {
+        for (int ks = 0; ks < KS; ks++) dst[ks] = *(const bf16x8*)(qp + ks * 16);          // all loads first (attention.hip: the prescale inside the loop
+        if (p.q_prescale != 1.0f) {                                                         // made hipcc wait for every load in turn)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) dst[ks][e] = f2bf(bf2f(dst[ks][e]) * p.q_prescale);
-            }
         }
     };
     // q . k_cls over this lane's 32 of the 64 dimensions, both halves summed
