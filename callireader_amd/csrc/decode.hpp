@@ -2,7 +2,7 @@
 #pragma once
 #include "common.hpp"
 
-constexpr int DECODE_FUSED_MAX_ROWS = 4;     // beyond this the separate kernels are faster (gemm_decode.hip's header, profiles/round4/)
+constexpr int DECODE_FUSED_MAX_ROWS = 8;     // beyond this the separate kernels are faster (gemm_decode.hip's header, profiles/round4/)
 
 enum DecodeGemm { DEC_WQKV = 0, DEC_WO = 1, DEC_W13 = 2, DEC_W2 = 3, DEC_HEAD = 4 };
 

@@ -1,7 +1,7 @@
 // Small-batch decode (M <= DECODE_FUSED_MAX_ROWS rows): the five linear layers of an InternLM2 decoder layer and the LM head, each with the row-wise
 // kernels around it folded in, so that a decoder layer is SIX launches instead of nine (round-3 verdict, item 2).  Used for up to
-// DECODE_FUSED_MAX_ROWS rows: a normalised row costs 8 KiB of every workgroup's LDS, and from 5 rows on that costs the weight streams
-// their occupancy (wqkv at 1 / 4 / 8 / 16 rows: 16.5 / 17.4 / 24.6 / 31.7 us against 13.5 + 4.6 + the norm's share for the separate kernels):
+// DECODE_FUSED_MAX_ROWS (8) rows: a normalised row costs 8 KiB of every workgroup's LDS; up to 8 rows two workgroups still fit a CU (ALIAS / TG
+// below), beyond that the weight streams lose their occupancy (wqkv at 16 rows: 31.7 us against 14.6 + 4.7 + the norm's share separately):
 //
 //   wqkv  : RMSNorm(x) prologue             -> GEMM -> RoPE + split epilogue: q rows, K / V straight into the cache
 //                                                       (modeling_internlm2.py:138-143, 359-388, 233-247)
@@ -36,26 +36,38 @@ constexpr int LIN_FLOATS = 16 * 17;
 enum { DEPI_ROPE = 100 };
 
 // PRO: X = RMSNorm(xres) built in LDS and read from there; otherwise X comes as fragment-shaped loads from L2, one batch ahead.
+// TG: tile groups per workgroup -- TG * KW waves, group tg = wave / KW works on tile base + tg, all groups share the normalised rows in LDS
+//     (w1|w3 and the LM head at 5..8 rows: 64 KiB of rows leave room for two workgroups per CU, so each brings eight waves).
+// ALIAS: one tile per workgroup (wqkv): the sums' staging area lies over the normalised rows, which are dead once every wave has left the
+//     main loop (one more barrier) -- 66 KiB instead of 84 at eight rows = two workgroups per CU instead of one.
 // (Measured and dropped: copying the activation rows of wo / w2 into LDS first -- 9.8 against 9.3 us for wo, 26.8 against 26.5 for w2 at
 // one row once two batches of weights are in flight; hoisting the prologue's row loads; a one-wave-per-row prologue.)
-template <int EPI, int KW, int VS, int KPR, bool PRO>
-__global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const DecodeGemmParams p) {      // PRO forms: 128 registers, 16 waves per CU
+template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false>
+__global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const DecodeGemmParams p) {      // PRO forms: 128 registers, 16 waves per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = VS * KPR;            // 32-deep k-steps per wave and tile
     constexpr int UB = 8;                  // k-steps per register batch; two batches of weight loads are in flight
     static_assert(T % UB == 0 && T / UB >= 2, "whole batches, at least two");
+    static_assert(!ALIAS || (PRO && TG == 1), "aliasing is for the one-tile-per-workgroup prologue form");
     constexpr int NB = T / UB;
-    float* red = (float*)smem;                                   // [KW][VS][16][17]
-    float* lin = red + KW * VS * LIN_FLOATS;                     // [16][17]: the finished sums of a tile
-    char* xlds = (char*)(lin + LIN_FLOATS);                      // PRO: [M][XROW]
+    constexpr int NTHREADS = TG * KW * 64;
     const int XROW = p.K * 2 + 16;                               // bytes per row in LDS: 16 rows land on 16 different bank groups
+    // LDS: [sums: TG x KW x VS tiles of 16 x 17 floats][finished sums: TG tiles][norm scratch: 64 B][PRO: M normalised rows]; ALIAS puts the rows at 0
+    constexpr int RED_FLOATS = TG * KW * VS * LIN_FLOATS;
+    float* red = (float*)smem;
+    float* lin = red + RED_FLOATS;                               // [TG][16][17]
+    char* xlds = ALIAS ? smem : (char*)(lin + TG * LIN_FLOATS) + 64;
+    float* nred = ALIAS ? (float*)(smem + (size_t)p.M * XROW) : (float*)(lin + TG * LIN_FLOATS);      // 4 floats per 256-thread group of the prologue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave / KW, kp = wave % KW;                    // tile group, K part
     const int kq = (lane >> 4) * 8;
     const int xm = min(lane & 15, p.M - 1);
     const int ntiles = (p.N + 15) / 16;
-    const int en = tid & 15, em = (tid >> 4) & 15;               // epilogue: thread -> (tile row n, batch row m), threads 0..255
-    const bool elive = tid < 256 && em < p.M;
+    const int et = tid & 255, etg = tid >> 8;                    // epilogue: 256 threads per tile group -> (tile row n, batch row m)
+    const int en = et & 15, em = et >> 4;
+    const bool ethread = etg < TG;                               // (KW = 8: threads 256..511 of a one-group workgroup have no epilogue element)
+    red += tg * KW * VS * LIN_FLOATS;
 
     auto wrow = [&](int tile, int r) -> int {
         if (EPI == DEPI_ROPE) {            // head slot gs = tile / 8: rows 8j..8j+7 of its first half and the 8 rows 64 further on
@@ -64,11 +76,12 @@ __global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const
         }
         return min(tile * 16 + r, p.N - 1);
     };
-    // flat k-step i of this wave: slice s = i / KPR, step j = i % KPR of the range (s*KW + wave) * KPR
-    auto koff = [&](int i) -> int { return (((i / KPR) * KW + wave) * KPR + (i % KPR)) * 32; };
+    // flat k-step i of this wave: slice s = i / KPR, step j = i % KPR of the range (s*KW + kp) * KPR
+    auto koff = [&](int i) -> int { return (((i / KPR) * KW + kp) * KPR + (i % KPR)) * 32; };
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    int base = blockIdx.x * TG;                                  // first tile of this workgroup's current set (workgroup-uniform loop)
+    if (base >= ntiles) return;
+    int tile = min(base + tg, ntiles - 1);                       // a group past the last tile recomputes it and stores nothing
     bf16x8 wr[2][UB];
     auto load_w = [&](bf16x8 (&dst)[UB], const bf16* wp, int b) {
 #pragma unroll
@@ -79,11 +92,13 @@ __global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const
     if (!PRO) load_w(wr[1], wp, 1);                              // (the RMSNorm prologue needs the registers: its second batch follows it)
 
     // what the epilogue will need from memory, requested now: its round trips end long before the sums do
+    const int etile0 = min(base + etg, ntiles - 1);
+    const bool elive0 = ethread && em < p.M && base + etg < ntiles;
     float xpre = 0.f, cs = 0.f, sn = 0.f;
     int seq = 0, pos = 0;
-    if (EPI == EPI_RES && elive) xpre = bf2f(p.xio[(int64_t)em * D4 + tile * 16 + en]);
-    if (EPI == DEPI_ROPE && elive) {
-        const int j8 = tile & 7, c = en < 8 ? 8 * j8 + en : 64 + 8 * j8 + (en - 8);
+    if (EPI == EPI_RES && elive0) xpre = bf2f(p.xio[(int64_t)em * D4 + etile0 * 16 + en]);
+    if (EPI == DEPI_ROPE && elive0) {
+        const int j8 = etile0 & 7, c = en < 8 ? 8 * j8 + en : 64 + 8 * j8 + (en - 8);
         seq = p.seqs[em]; pos = p.lens[seq];
         cs = bf2f(p.cosT[(int64_t)pos * HD + c]); sn = bf2f(p.sinT[(int64_t)pos * HD + c]);
     }
@@ -91,13 +106,13 @@ __global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const
     if (PRO) {
         // RMSNorm of the M residual rows into LDS (measured and dropped: one wave per row without barriers -- the row held in registers
         // beside the weight loads spills at 128 registers, re-reading it costs a second round trip: 18.7 against 16.4 us for wqkv at one row)
-        constexpr int NG = KW * 64 / 256;                         // 256 threads per row: norm.hip's own layout and function
+        constexpr int NG = NTHREADS / 256;                        // 256 threads per row: norm.hip's own layout and function
         const int g = tid >> 8, t = tid & 255;
         for (int m0 = 0; m0 < p.M; m0 += NG) {
             const int m = m0 + g;
             float x[16], y[16];
             load16(p.xres + (int64_t)min(m, p.M - 1) * D4 + t * 16, x);
-            rmsnorm_row16(x, p.gamma + t * 16, p.eps, red + g * 4, t, y);
+            rmsnorm_row16(x, p.gamma + t * 16, p.eps, nred + g * 4, t, y);
             if (m < p.M) store16((bf16*)(xlds + (size_t)m * XROW) + t * 16, y);
         }
         __syncthreads();
@@ -116,9 +131,11 @@ __global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const
 #pragma unroll
             for (int u = 0; u < UB; u++) xr[0][u] = *(const bf16x8*)(xg + koff(u));
         }
-        const int next = tile + gridDim.x;
+        const int nbase = base + gridDim.x * TG;
+        const bool has_next = nbase < ntiles;                    // workgroup-uniform
+        const int ntile = min(nbase + tg, ntiles - 1);
         const bf16* wpn = wp;
-        if (next < ntiles) wpn = p.W + (int64_t)wrow(next, lane & 15) * p.ldw + kq;
+        if (has_next) wpn = p.W + (int64_t)wrow(ntile, lane & 15) * p.ldw + kq;
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             if (XL) {
@@ -136,46 +153,51 @@ __global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const
             // the register set just consumed takes batch b + 2 -- of this tile, or the first two of the next one (they travel under the reduction)
             if (b + 2 < NB) {
                 load_w(wr[b & 1], wp, b + 2);
-            } else if (next < ntiles) {
+            } else if (has_next) {
                 load_w(wr[b & 1], wpn, b + 2 - NB);
             }
         }
         wp = wpn;
+        if (ALIAS) __syncthreads();                              // every wave is done with the normalised rows: the sums may land on them
         // C^T tile: n = (lane >> 4) * 4 + e, m = lane & 15
 #pragma unroll
         for (int s = 0; s < VS; s++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) red[((wave * VS + s) * 16 + (lane >> 4) * 4 + e) * 17 + (lane & 15)] = acc[s][e];
+            for (int e = 0; e < 4; e++) red[((kp * VS + s) * 16 + (lane >> 4) * 4 + e) * 17 + (lane & 15)] = acc[s][e];
         __syncthreads();
-        if (tid < 256) {
+        const int etile = base + etg;
+        const bool elive = ethread && em < p.M && etile < ntiles;
+        if (ethread) {
+            const float* rg = (const float*)smem + etg * KW * VS * LIN_FLOATS;
             float a = 0.f;
 #pragma unroll
             for (int s = 0; s < VS; s++) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < KW; w++) v += red[((w * VS + s) * 16 + en) * 17 + em];       // the waves' tiles in wave order
+                for (int w = 0; w < KW; w++) v += rg[((w * VS + s) * 16 + en) * 17 + em];         // the waves' tiles in wave order
                 if (VS == 1) a = v; else a += v;                                                  // the slices in slice order, from 0.f
             }
-            lin[en * 17 + em] = a;
+            lin[etg * LIN_FLOATS + en * 17 + em] = a;
         }
         __syncthreads();
         if (elive) {
+            const float* lt = lin + etg * LIN_FLOATS;
             if (EPI == EPI_RES) {
                 // add_rmsnorm4096_kernel's first half: x = bf16(x + bf16(sum))
-                p.xio[(int64_t)em * D4 + tile * 16 + en] = f2bf(rbf(xpre + rbf(lin[en * 17 + em])));
+                p.xio[(int64_t)em * D4 + etile * 16 + en] = f2bf(rbf(xpre + rbf(lt[en * 17 + em])));
             } else if (EPI == EPI_SWIGLU) {
                 if (en < 8) {
-                    const float gt = rbf(lin[en * 17 + em]), up = rbf(lin[(8 + en) * 17 + em]);
-                    ((bf16*)p.C)[(int64_t)em * p.ldc + tile * 8 + en] = f2bf(rbf(silu(gt)) * up);
+                    const float gt = rbf(lt[en * 17 + em]), up = rbf(lt[(8 + en) * 17 + em]);
+                    ((bf16*)p.C)[(int64_t)em * p.ldc + etile * 8 + en] = f2bf(rbf(silu(gt)) * up);
                 }
             } else if (EPI == EPI_F32) {
-                const int gn = tile * 16 + en;
-                if (gn < p.N) ((float*)p.C)[(int64_t)em * p.ldc + gn] = rbf(lin[en * 17 + em] + 0.f);
+                const int gn = etile * 16 + en;
+                if (gn < p.N) ((float*)p.C)[(int64_t)em * p.ldc + gn] = rbf(lt[en * 17 + em] + 0.f);
             } else if (EPI == DEPI_ROPE) {
                 // rope_split_kernel: the bf16 linear output, rotated (slots 0..4 of a group: 4 q heads and k), split into q rows and the cache
-                const int gs = tile >> 3, j8 = tile & 7, grp = gs / 6, slot = gs - grp * 6;
+                const int gs = etile >> 3, j8 = etile & 7, grp = gs / 6, slot = gs - grp * 6;
                 const int c = en < 8 ? 8 * j8 + en : 64 + 8 * j8 + (en - 8);
-                const bf16 xb = f2bf(lin[en * 17 + em]), xpb = f2bf(lin[(en ^ 8) * 17 + em]);
+                const bf16 xb = f2bf(lt[en * 17 + em]), xpb = f2bf(lt[(en ^ 8) * 17 + em]);
                 bf16 y = xb;
                 if (slot < 5) {
                     const float sign = c < 64 ? -1.0f : 1.0f;        // rotate_half: (-x2, x1)
@@ -187,25 +209,28 @@ __global__ __launch_bounds__(KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const
                 dst[c] = y;
             }
         }
-        if (next >= ntiles) break;
-        tile = next;
-        if (EPI == EPI_RES && elive) xpre = bf2f(p.xio[(int64_t)em * D4 + tile * 16 + en]);
-        __syncthreads();                                         // lin / red are rewritten by the next tile
+        if (!has_next) break;
+        base = nbase;
+        tile = ntile;
+        if (EPI == EPI_RES && ethread && em < p.M && base + etg < ntiles) xpre = bf2f(p.xio[(int64_t)em * D4 + (base + etg) * 16 + en]);
+        __syncthreads();                                         // lin / red are rewritten by the next set of tiles
     }
 }
 
-template <int KW, int VS>
-constexpr int fixed_lds() { return (KW * VS + 1) * LIN_FLOATS * 4; }
+template <int KW, int VS, int TG>
+constexpr int fixed_lds() { return TG * (KW * VS + 1) * LIN_FLOATS * 4 + 64; }
 
-template <int EPI, int KW, int VS, int KPR, bool PRO>
+template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false>
 int launch_one(const DecodeGemmParams& p, int grid_cap, hipStream_t st) {
     const int ntiles = (p.N + 15) / 16;
-    const int lds = fixed_lds<KW, VS>() + (PRO ? p.M * (p.K * 2 + 16) : 0);
-    if (lds > 160 * 1024) return CR_ERR_ARG;
+    const int sets = (ntiles + TG - 1) / TG;
+    const int xbytes = PRO ? p.M * (p.K * 2 + 16) : 0;
+    const int lds = ALIAS ? (xbytes + 64 > fixed_lds<KW, VS, TG>() ? xbytes + 64 : fixed_lds<KW, VS, TG>()) : fixed_lds<KW, VS, TG>() + xbytes;
+    if (lds > 160 * 1024 || (ALIAS && grid_cap != 0)) return CR_ERR_ARG;
     static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO>, 160 * 1024)) return CR_ERR_HIP;
-    const int grid = grid_cap > 0 && grid_cap < ntiles ? grid_cap : ntiles;
-    hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO>), dim3(grid), dim3(KW * 64), lds, st, p);
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS>, 160 * 1024)) return CR_ERR_HIP;
+    const int grid = grid_cap > 0 && grid_cap < sets ? grid_cap : sets;
+    hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS>), dim3(grid), dim3(TG * KW * 64), lds, st, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
@@ -234,18 +259,20 @@ static int launch_decode_gemm_(int which, const DecodeGemmParams& p, hipStream_t
     switch (which) {
         case DEC_WQKV:
             if (p.N != 6144 || p.K != 4096 || !p.xres || !p.gamma || !p.cosT || !p.sinT || !p.q_out || !p.kc || !p.vc || !p.seqs || !p.lens) return CR_ERR_ARG;
-            return launch_one<DEPI_ROPE, 8, 2, 8, true>(p, 0, st);
+            return launch_one<DEPI_ROPE, 8, 2, 8, true, 1, true>(p, 0, st);              // one tile per workgroup: sums alias the normalised rows
         case DEC_WO:
             if (p.N != 4096 || p.K != 4096 || !p.X || !p.xio) return CR_ERR_ARG;
             return launch_one<EPI_RES, 8, 4, 4, false>(p, 0, st);
         case DEC_W13:
             if (p.N != 2 * 14336 || p.K != 4096 || !p.xres || !p.gamma || !p.C) return CR_ERR_ARG;
+            if (p.M > 4) return launch_one<EPI_SWIGLU, 4, 1, 32, true, 2>(p, g13 / 2, st);      // two tiles at a time on shared rows: 16 waves per CU at 5..8 rows
             return launch_one<EPI_SWIGLU, 4, 1, 32, true>(p, g13, st);
         case DEC_W2:
             if (p.N != 4096 || p.K != 14336 || !p.X || !p.xio) return CR_ERR_ARG;
             return launch_one<EPI_RES, 8, 4, 14, false>(p, 0, st);
         case DEC_HEAD:
             if (p.K != 4096 || !p.xres || !p.gamma || !p.C) return CR_ERR_ARG;
+            if (p.M > 4) return launch_one<EPI_F32, 4, 1, 32, true, 2>(p, ghead / 2, st);
             return launch_one<EPI_F32, 4, 1, 32, true>(p, ghead, st);
     }
     return CR_ERR_ARG;

@@ -228,7 +228,7 @@ int cr_op_norm_fp8(const void* in, const void* gamma, const void* beta, int64_t 
 /* C8 = e4m3(bf16(gelu(bf16((A8 . W8^T) * ascale[m] * wscale[n] + bias))) / c8scale[m]), bytes [M][N]: fc1's output as fc2's operand */
 int cr_op_gemm_q8(const void* a8, const float* ascale, const void* w8, const float* wscale, const void* bias, const float* c8scale,
                   void* c8, int M, int N, int K, void* stream);
-/* One small-batch decode GEMM with its neighbours folded in (gemm_decode.hip; M <= 4 rows, InternLM2.5-7B shapes): which = 0 wqkv
+/* One small-batch decode GEMM with its neighbours folded in (gemm_decode.hip; M <= 8 rows, InternLM2.5-7B shapes): which = 0 wqkv
  * [RMSNorm(xres) -> GEMM -> RoPE + split: q_out rows, K / V rows into kc / vc at (seqs[m], lens[seqs[m]])], 1 wo [X -> GEMM -> xio += ],
  * 2 w1|w3 [RMSNorm(xres) -> GEMM -> SwiGLU -> C], 3 w2 [as 1], 4 LM head [RMSNorm(xres) -> GEMM -> fp32 C].  Replaces, per decode step of
  * InternLM2DecoderLayer.forward (modeling_internlm2.py:621-681): the norm / linear / rotary / residual statements around each linear.

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from callireader_amd import engine as E
 
-ROWS = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
+ROWS = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(0)
 D, FF, V, QKV = 4096, 14336, 92553, 6144

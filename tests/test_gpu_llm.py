@@ -150,11 +150,12 @@ def test_batched_decode_equals_single(setup):
     kv.free()
 
 
-@pytest.mark.parametrize('rows', [1, 2, 3, 4, 5])
+@pytest.mark.parametrize('rows', [1, 2, 3, 4, 5, 7, 8, 9])
 def test_fused_small_batch_decode_gives_the_separate_kernels_bits(setup, rows):
-    """Batches of <= 4 rows decode through gemm_decode.hip (RMSNorm prologues, RoPE + cache-write epilogue, residual-add epilogues: six
+    """Batches of <= 8 rows decode through gemm_decode.hip (RMSNorm prologues, RoPE + cache-write epilogue, residual-add epilogues: six
     launches per layer); CR_DECODE_FUSED=0 keeps the separate kernels.  Logits, cache rows and ids must be the SAME BITS, step after step:
-    a row's result may not depend on which path its batch size selects (a 5-row batch takes the separate kernels in both engines)."""
+    a row's result may not depend on which path its batch size selects (a 9-row batch takes the separate kernels in both engines;
+    5..8 rows take the two-tiles-per-workgroup forms of w1|w3 and the LM head)."""
     import os
     from callireader_amd.engine import Engine
     eng = setup['eng']
