@@ -236,7 +236,8 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     p.bias = (const bf16*)bias; p.scale = (const bf16*)scale; p.res = (const bf16*)res; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K; p.group = group;
     const int kern = (epi >> 8) & 0xff;           // tests pin a kernel: 1 = 128x128, 2 = 256x256, 3 = skinny
-    p.kernel = kern == 1 ? 128 : kern == 2 ? 256 : kern == 3 ? 1 : 0;
+    p.kernel = kern == 1 ? 128 : (kern == 2 || kern == 5 || kern == 6) ? 256 : kern == 3 ? 1 : 0;
+    p.slots = kern == 5 ? 16 : kern == 6 ? 32 : 0;            // 5 / 6: the 256x256 kernel with its 16- / 32-MFMA-slot schedule pinned
     if (epi & (1 << 16)) { p.w8 = 1; p.wscale = (const float*)scale; p.scale = nullptr; }      // e4m3 weights + per-row fp32 scales
     if (epi & (1 << 17)) { p.a8 = 1; p.ascale = (const float*)res; p.res = nullptr; }          // e4m3 activations too: `res` = fp32 row scales [M]
     epi &= 0xff;

@@ -164,6 +164,7 @@ struct GemmParams {
     int M, N, K;
     int group;                 // EPI_PATCH: patches per tile (1024)
     int kernel;                // 0 = dispatcher's choice; 128 | 256 | 1 (skinny) pin one (cr_op_gemm's tests only)
+    int slots;                 // gemm256 only: 0 = schedule picked per shape; 16 | 32 pin one of its two schedules (tests: the same bits)
     // fp8 weight streaming (decode, M <= 64 only): W points at e4m3 bytes [N][ldw], wscale[n] restores row n (C = (X . W8^T) * wscale)
     int w8;
     const float* wscale;

@@ -781,7 +781,8 @@ int launch_s(const GemmParams& p, hipStream_t stream) {
 template <int EPI, bool F8 = false>
 int launch_t(const GemmParams& p, hipStream_t stream) {
     static const int pin = [] { const char* e = getenv("CR_GEMM_SLOTS"); return e ? atoi(e) : 0; }();
-    const bool big = !F8 && (pin == 32 || (pin != 16 && p.N >= 2048 && p.K <= 8192));
+    const int want = p.slots ? p.slots : pin;
+    const bool big = !F8 && (want == 32 || (want != 16 && p.N >= 2048 && p.K <= 8192));
     if constexpr (!F8) { if (big) return launch_s<EPI, false, true>(p, stream); }
     return launch_s<EPI, F8, false>(p, stream);
 }

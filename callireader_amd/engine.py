@@ -272,7 +272,8 @@ class KVCache:
 
 # ---- single operators (tests / profiling) ----
 def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None, kernel=0, out=None):
-    """kernel: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent, 3 weight-streaming (tests pin one)."""
+    """kernel: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent (schedule per shape), 3 weight-streaming, 5 / 6 the 256x256 kernel with
+    its 16- / 32-MFMA-slot schedule pinned (tests pin one)."""
     M, K = A.shape
     N = Wt.shape[0]
     ncols = n_out if n_out is not None else (N // 2 if epi == 4 else N)

@@ -206,7 +206,8 @@ int cr_orderformer(cr_ctx* ctx, const void* boxes, int B, int L, float* scores, 
  * 8 row arg-max partials (cosine VQ: C = uint64 [M][ldc], one per row and 64-column block: bits of the bf16-rounded maximum in the
  *   high word, its first column in the low word; M > 64 tile kernels only).
  * Bits 8..15 of epi pin a kernel for the unit tests: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent,
- * 3 weight-streaming (M <= 64); a pinned kernel that cannot take the shape returns CR_ERR_ARG. */
+ * 3 weight-streaming (M <= 64), 5 / 6 the 256x256 kernel with its 16- / 32-MFMA-slot schedule (the same sums: the same bits);
+ * a pinned kernel that cannot take the shape returns CR_ERR_ARG. */
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
                void* stream);

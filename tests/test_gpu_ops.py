@@ -618,6 +618,34 @@ def test_attention_softmax_spike(E):
     torch.testing.assert_close(o.float(), ref, rtol=RTOL, atol=1.5e-2)
 
 
+@pytest.mark.parametrize('M,N,K', [(2304, 768, 256), (4100, 1024, 640 + 128), (5000, 2304, 1024), (2049, 512, 128)])
+def test_gemm256_both_schedules_give_the_same_bits(E, M, N, K):
+    """The 256x256 kernel has two schedules of the same sums (16- and 32-MFMA matrix slots, round 4); the launcher picks one per shape, so a
+    shape's bits may not depend on the pick: every epilogue that has both instances, random data, exact equality, plus the integer-exact
+    reference for the plain store."""
+    g = torch.Generator().manual_seed(900 + M)
+    A = bf(_rand((M, K), g)).to(dev())
+    W = bf(_rand((N, K), g, 0.05)).to(dev())
+    bias = bf(_rand((N,), g, 0.1)).to(dev())
+    scale = bf(_rand((N,), g)).to(dev())
+    res = bf(_rand((M, N), g)).to(dev())
+    for epi, kw in ((0, dict(bias=bias)), (1, dict(bias=bias)), (2, dict(bias=bias, scale=scale, res=res)), (3, dict(res=res)), (6, dict(bias=bias, out_dtype=torch.float32))):
+        a = E.op_gemm(epi, A, W, kernel=5, **kw)
+        b = E.op_gemm(epi, A, W, kernel=6, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (epi, float((a.float() - b.float()).abs().max()))
+    if N % 16 == 0:
+        a = E.op_gemm(4, A, W, kernel=5)
+        b = E.op_gemm(4, A, W, kernel=6)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    Ai = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16).to(dev())
+    Wi = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16).to(dev())
+    ref = (Ai.float() @ Wi.float().t()).to(torch.bfloat16)
+    for kern in (5, 6):
+        assert torch.equal(E.op_gemm(0, Ai, Wi, kernel=kern), ref), kern
+
+
 @pytest.mark.parametrize('epi', [1, 2])
 def test_gemm256_launches_back_to_back_are_identical(E, epi):
     """The persistent 256x256 kernel keeps LDS-DMA in flight across raw barriers and (GELU) reads its table beside them: the same
