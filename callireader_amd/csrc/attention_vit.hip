@@ -121,6 +121,16 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
 #pragma unroll
         for (int ii = 0; ii < IPW; ii++) {
             const unsigned dst = smem_base + buf * (2 * TILE) + (wave * IPW + ii) * 1024;
+#ifdef CR_POISON     // hazard screen (diagnostic build): the two 1-KiB pieces about to be refilled hold bf16 NaNs until the new bytes land (gemm256.hip explains)
+            {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_p;
+                const u32x4_p nan4 = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+                char* pz = smem + buf * (2 * TILE) + (wave * IPW + ii) * 1024 + lane * 16;
+                *(u32x4_p*)pz = nan4;
+                *(u32x4_p*)(pz + TILE) = nan4;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#endif
             dma16(ksrc[ii], k_voff[ii], dst);
             dma16(vsrc[ii], v_voff, dst + TILE);
             ksrc[ii] += k_step;

@@ -73,7 +73,13 @@ constexpr int LDS_MAIN2 = 2 * KBUF;               // 131072
 constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per wave = 163840 (all of the CU's LDS)
 
 #define WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#ifdef CR_BREAK_WAIT    // diagnostic (scripts/hazard_teeth.py): NO counted wait in the main loop and none after the cold-start fills
+#define WAIT_VM8() asm volatile("s_waitcnt vmcnt(63)" ::: "memory")
+#define WAIT_COLD() asm volatile("s_waitcnt vmcnt(63)" ::: "memory")
+#else
 #define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define WAIT_COLD() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #ifdef CR_KO_STORE      // diagnostic build: the plain-store epilogue keeps its values alive but sends nothing (wrong results)
 #define CR_STORE_OUT(v, ptr) asm volatile("" ::"v"(v), "v"(ptr))
@@ -549,6 +555,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     };
     auto dma = [&](const bf16* base, uint32_t o, int kt, int buf, int u) {
         char* dst = smem + buf * KBUF + u * UNIT + (2 * wave) * 1024;
+#ifdef CR_POISON
+        // Hazard screen (diagnostic build): the two sub-tiles this wave is about to refill are overwritten with bf16 NaNs
+        // first.  By the schedule's WAR rule nobody may still read them, by its RAW rule nobody reads them again before the new bytes have landed: a
+        // read that breaks either rule now returns NaNs and the integer-exact tests fail instead of passing by luck (tests/test_gpu_ops.py runs them
+        // on this build).
+        {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_p;
+            const u32x4_p nan4 = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+            *(u32x4_p*)(dst + lane * 16) = nan4;
+            *(u32x4_p*)(dst + 1024 + lane * 16) = nan4;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#endif
         const char* src = (const char*)base + (int64_t)kt * (BK2 * 2);
         __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst), 16, 0, 0);
         // the instruction's immediate offset is added to the global AND to the LDS address: M0 is set 64 short
@@ -643,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     if (BIG) dma(p.W, qB[1], 1, 1, 2);                         // (32-MFMA slots: phase 1 of the first pair stages U3 of K-tile 1)
     if (EPI == EPI_GELU) gelu_lut_fill(smem + LDS_MAIN2, tid);      // under the cold-start fills; the barrier below publishes it
     if (EPI == EPI_GELU) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table's ds_writes, explicitly (free under the DMA wait)
-    WAIT_VM0();
+    WAIT_COLD();
     __builtin_amdgcn_s_barrier();
 
     while (true) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Development aid: build ab/lib<name>.so = the library with ONE source recompiled under extra flags (A/B runs select it
-with CR_HIP_LIB=ab/lib<name>.so).  usage: build_variant.py <name> <source.hip> [-DFOO=1 ...]"""
+"""Development aid: build ab/lib<name>.so = the library with ONE source (or several, comma-separated) recompiled under extra flags (A/B runs
+select it with CR_HIP_LIB=ab/lib<name>.so).  usage: build_variant.py <name> <source.hip[,other.hip]> [-DFOO=1 ...]"""
 import os
 import subprocess
 import sys
@@ -13,10 +13,14 @@ name, src = sys.argv[1], sys.argv[2]
 flags = sys.argv[3:]
 B.build()
 os.makedirs(os.path.join(ROOT, 'ab'), exist_ok=True)
-obj = os.path.join(ROOT, 'ab', f'{name}_{src[:-4]}.o')
-cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + B.EXTRA_FLAGS.get(src, []) + flags + ['-c', os.path.join(B.CSRC, src), '-o', obj]
-subprocess.check_call(cmd)
-objs = [os.path.join(B.CSRC, 'build', os.path.basename(s)[:-4] + '.o') for s in B.sources() if os.path.basename(s) != src] + [obj]
+srcs = src.split(',')
+new_objs = []
+for one in srcs:
+    obj = os.path.join(ROOT, 'ab', f'{name}_{one[:-4]}.o')
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + B.EXTRA_FLAGS.get(one, []) + flags + ['-c', os.path.join(B.CSRC, one), '-o', obj]
+    subprocess.check_call(cmd)
+    new_objs.append(obj)
+objs = [os.path.join(B.CSRC, 'build', os.path.basename(s)[:-4] + '.o') for s in B.sources() if os.path.basename(s) not in srcs] + new_objs
 out = os.path.join(ROOT, 'ab', f'lib{name}.so')
 subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
 print(out)
