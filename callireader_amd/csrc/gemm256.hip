@@ -602,9 +602,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // a phase = a memory slot (fragment reads of this phase, one unit's two DMA pieces, the counted wait) and a
     // matrix slot (16 MFMAs), each closed by s_barrier.  Waves 4..7 run one slot behind waves 0..3, so on every
     // SIMD one wave's matrix slot runs beside its partner's memory slot.
+#ifdef CR_KI_VALU   // knock-in diagnostic (HISTORY.md): CR_KI_VALU independent vector instructions in every memory slot -- is vector issue free there?
+#define KI_VALU() _Pragma("unroll") for (int q_ = 0; q_ < CR_KI_VALU; q_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(ki[q_ & 3]))
+#else
+#define KI_VALU()
+#endif
 #define MEM_SLOT_B(READS, DMA, WAIT)      /* 32-MFMA schedule: the reads are retired in front of the slot's barrier */ \
     READS;                                                                                      \
     DMA;                                                                                        \
+    KI_VALU();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     if (WAIT) WAIT_VM8();                                                                       \
     WAIT_LGKM0();                                                                               \
@@ -613,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #define MEM_SLOT(READS, DMA, WAIT)                                                              \
     READS;                                                                                      \
     DMA;                                                                                        \
+    KI_VALU();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     if (WAIT) WAIT_VM8();                                                                       \
     __builtin_amdgcn_s_barrier();
@@ -651,6 +658,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_barrier();
 
+#ifdef CR_KI_VALU
+    float ki[4] = {1.f, 1.f, 1.f, 1.f};
+#endif
     int t_cur = blockIdx.x;
     if (t_cur >= ntiles) return;
     int m0, n0;
