@@ -254,8 +254,10 @@ int launch_decode_gemm(int which, const DecodeGemmParams& p, hipStream_t st) {
 }
 
 static int launch_decode_gemm_(int which, const DecodeGemmParams& p, hipStream_t st) {
-    // persistent grids (tuning aids): w1|w3 has 1792 tiles = 7 per CU, the LM head 5785
-    static const int g13 = env_int("CR_DEC_GRID13", 896), ghead = env_int("CR_DEC_GRIDHEAD", 1024);
+    // persistent grids: w1|w3 has 1792 tiles, the LM head 5785.  Two 256-thread workgroups per CU (one 512-thread one at 5..8 rows) measured best at every row
+    // count (w1|w3 at one row, us: 256 -> 43.6, 512 -> 42.5, 640 -> 46.4, 768 -> 43.3, 896 -> 47.9, 1024 -> 42.9, 1792 -> 44.3; at eight rows 49.8 / 51.2 for 512 / 896):
+    // every workgroup repeats the RMSNorm prologue, and a grid that is not a multiple of the 256 CUs leaves some of them a workgroup short
+    static const int g13 = env_int("CR_DEC_GRID13", 512), ghead = env_int("CR_DEC_GRIDHEAD", 512);
     switch (which) {
         case DEC_WQKV:
             if (p.N != 6144 || p.K != 4096 || !p.xres || !p.gamma || !p.cosT || !p.sinT || !p.q_out || !p.kc || !p.vc || !p.seqs || !p.lens) return CR_ERR_ARG;
