@@ -293,9 +293,16 @@ int cr_op_decode_gemm(int which, int flags, const void* W, int64_t ldw, int M, i
     DecodeGemmParams p{};
     p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.X = (const bf16*)X; p.ldx = ldx; p.xres = (const bf16*)xres;
     p.gamma = (const bf16*)gamma; p.eps = eps; p.xio = (bf16*)xio; p.C = C; p.ldc = ldc; p.cosT = (const bf16*)cosT; p.sinT = (const bf16*)sinT;
-    p.q_out = (bf16*)q_out; p.kc = (bf16*)kc; p.vc = (bf16*)vc; p.seqs = seqs; p.lens = lens; p.max_tokens = max_tokens; p.flags = flags;
+    p.q_out = (bf16*)q_out; p.kc = (bf16*)kc; p.vc = (bf16*)vc; p.seqs = seqs; p.lens = lens; p.max_tokens = max_tokens; p.flags = flags & 255;
+    p.swizzled = (flags >> 8) & 1;
     const int r = launch_decode_gemm(which, p, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_decode_gemm(which=%d, M=%d, N=%d, K=%d) rejected or failed to launch", which, M, N, K);
+    return CR_OK;
+}
+
+int cr_op_decode_swizzle(int which, const void* W, int64_t ldw, int N, int K, void* dst, void* stream) {
+    const int r = decode_swizzle_weight(which, (const bf16*)W, ldw, N, K, (bf16*)dst, (hipStream_t)stream);
+    if (r != CR_OK) return cr_fail(r, "cr_op_decode_swizzle(which=%d, N=%d, K=%d) rejected or failed to launch", which, N, K);
     return CR_OK;
 }
 

@@ -7,7 +7,8 @@ constexpr int DECODE_FUSED_MAX_ROWS = 8;     // beyond this the separate kernels
 enum DecodeGemm { DEC_WQKV = 0, DEC_WO = 1, DEC_W13 = 2, DEC_W2 = 3, DEC_HEAD = 4 };
 
 struct DecodeGemmParams {
-    const bf16* W; int64_t ldw;          // [N][K] as nn.Linear stores it (w1|w3: the interleaved derived tensor)
+    const bf16* W; int64_t ldw;          // [N][K] as nn.Linear stores it (w1|w3: the interleaved derived tensor) -- or, with `swizzled`, its decode layout
+    int swizzled;                        //   (decode_swizzle_weight: 1 KiB per 16-row tile and 32-deep k-step; ldw unused)
     int M, N, K;
     const bf16* X; int64_t ldx;          // DEC_WO / DEC_W2: activations [M][K]
     const bf16* xres;                    // DEC_WQKV / DEC_W13 / DEC_HEAD: residual rows [M][4096] the prologue normalises
@@ -25,3 +26,6 @@ struct DecodeGemmParams {
 
 bool decode_fused_supported(int M, int ff);
 int launch_decode_gemm(int which, const DecodeGemmParams& p, hipStream_t stream);
+// the decode layout of one of the five weights (DEC_WQKV bakes the RoPE tile order in): `dst` holds decode_swizzled_bytes(N, K)
+size_t decode_swizzled_bytes(int N, int K);
+int decode_swizzle_weight(int which, const bf16* W, int64_t ldw, int N, int K, bf16* dst, hipStream_t stream);

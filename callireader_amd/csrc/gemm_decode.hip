@@ -23,7 +23,9 @@
 //   * RoPE needs column c and c +- 64 of a head together: a weight tile is 8 rows of a head's first half and the 8 rows 64 further on
 //     (which rows a workgroup owns changes no output element's sum), and the epilogue is rope_split_kernel's arithmetic.
 // Weight bytes are streamed once, non-temporally, straight to registers (two batches of eight 16-B loads per lane in flight); the
-// activations come from LDS (prologue forms) or from L2 (wo, w2: at most 16 rows).
+// activations come from LDS (prologue forms) or from L2 (wo, w2: at most 16 rows).  cr_finalize keeps every one of these weights a second time in
+// the DECODE LAYOUT (decode_swizzle_kernel: the 64 lanes' 16-byte fragments of one 16-row tile and 32-deep k-step side by side, 1 KiB), so a load
+// instruction is one contiguous KiB instead of 16 rows x 64 bytes: the four streams of a layer 95 -> 78 us at one row, a step 3.65 -> 3.10 ms.
 #include "common.hpp"
 #include "decode.hpp"
 #include "norm.hpp"
@@ -42,7 +44,10 @@ enum { DEPI_ROPE = 100 };
 //     main loop (one more barrier) -- 66 KiB instead of 84 at eight rows = two workgroups per CU instead of one.
 // (Measured and dropped: copying the activation rows of wo / w2 into LDS first -- 9.8 against 9.3 us for wo, 26.8 against 26.5 for w2 at
 // one row once two batches of weights are in flight; hoisting the prologue's row loads; a one-wave-per-row prologue.)
-template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false>
+// SW: the weights come in the decode layout (decode_swizzle_kernel below): one 1 KiB block per (16-row tile, 32-deep k-step), lane l's 16 bytes at l * 16 --
+//     a wave's load instruction reads ONE contiguous KiB instead of 16 rows x 64 bytes (scripts/ubench/persist_stream.hip: the four streams of a layer take
+//     68.5 us contiguous against 83.6 us row-wise; the same values in the same registers, so not a bit changes).
+template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false, bool SW = false>
 __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const DecodeGemmParams p) {      // PRO forms: 128 registers, 16 waves per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = VS * KPR;            // 32-deep k-steps per wave and tile
@@ -78,6 +83,11 @@ __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(
     };
     // flat k-step i of this wave: slice s = i / KPR, step j = i % KPR of the range (s*KW + kp) * KPR
     auto koff = [&](int i) -> int { return (((i / KPR) * KW + kp) * KPR + (i % KPR)) * 32; };
+    constexpr int WSTEP = SW ? 512 : 32;                          // elements between a lane's loads of consecutive k-steps
+    const int64_t tile_stride = (int64_t)(p.K / 32) * 512;       // SW: elements per tile
+    auto wbase = [&](int t) -> const bf16* {
+        return SW ? p.W + (int64_t)t * tile_stride + lane * 8 : p.W + (int64_t)wrow(t, lane & 15) * p.ldw + kq;
+    };
 
     int base = blockIdx.x * TG;                                  // first tile of this workgroup's current set (workgroup-uniform loop)
     if (base >= ntiles) return;
@@ -85,9 +95,9 @@ __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(
     bf16x8 wr[2][UB];
     auto load_w = [&](bf16x8 (&dst)[UB], const bf16* wp, int b) {
 #pragma unroll
-        for (int u = 0; u < UB; u++) dst[u] = __builtin_nontemporal_load((const bf16x8*)(wp + koff(b * UB + u)));
+        for (int u = 0; u < UB; u++) dst[u] = __builtin_nontemporal_load((const bf16x8*)(wp + (koff(b * UB + u) / 32) * WSTEP));
     };
-    const bf16* wp = p.W + (int64_t)wrow(tile, lane & 15) * p.ldw + kq;
+    const bf16* wp = wbase(tile);
     load_w(wr[0], wp, 0);                                        // travels under the prologue
     if (!PRO) load_w(wr[1], wp, 1);                              // (the RMSNorm prologue needs the registers: its second batch follows it)
 
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(
         const bool has_next = nbase < ntiles;                    // workgroup-uniform
         const int ntile = min(nbase + tg, ntiles - 1);
         const bf16* wpn = wp;
-        if (has_next) wpn = p.W + (int64_t)wrow(ntile, lane & 15) * p.ldw + kq;
+        if (has_next) wpn = wbase(ntile);
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             if (XL) {
@@ -220,18 +230,39 @@ __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(
 template <int KW, int VS, int TG>
 constexpr int fixed_lds() { return TG * (KW * VS + 1) * LIN_FLOATS * 4 + 64; }
 
-template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false>
+template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false, bool SW = false>
 int launch_one(const DecodeGemmParams& p, int grid_cap, hipStream_t st) {
+    if (!SW && p.swizzled) return launch_one<EPI, KW, VS, KPR, PRO, TG, ALIAS, true>(p, grid_cap, st);
     const int ntiles = (p.N + 15) / 16;
     const int sets = (ntiles + TG - 1) / TG;
     const int xbytes = PRO ? p.M * (p.K * 2 + 16) : 0;
     const int lds = ALIAS ? (xbytes + 64 > fixed_lds<KW, VS, TG>() ? xbytes + 64 : fixed_lds<KW, VS, TG>()) : fixed_lds<KW, VS, TG>() + xbytes;
     if (lds > 160 * 1024 || (ALIAS && grid_cap != 0)) return CR_ERR_ARG;
     static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS>, 160 * 1024)) return CR_ERR_HIP;
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW>, 160 * 1024)) return CR_ERR_HIP;
     const int grid = grid_cap > 0 && grid_cap < sets ? grid_cap : sets;
-    hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS>), dim3(grid), dim3(TG * KW * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW>), dim3(grid), dim3(TG * KW * 64), lds, st, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+// Decode layout of a weight matrix: dst[((tile * K/32 + kstep) * 64 + lane) * 8 + e] = W[row(tile, lane & 15)][kstep * 32 + (lane >> 4) * 8 + e], row() being the
+// consuming kernel's own tile -> row map (ROPE: gemm_decode_kernel<DEPI_ROPE>'s 8 + 8 rows of a head; rows past N repeat the last one).  One wave per block.
+template <bool ROPE>
+__global__ __launch_bounds__(256) void decode_swizzle_kernel(const bf16* __restrict__ W, int64_t ldw, int N, int K, bf16* __restrict__ dst) {
+    const int ksteps = K / 32;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (N + 15) / 16;
+    if (blk >= ntiles * ksteps) return;
+    const int tile = (int)(blk / ksteps), ks = (int)(blk % ksteps), r = lane & 15;
+    int row;
+    if (ROPE) {
+        const int gs = tile >> 3, j8 = tile & 7;
+        row = gs * HD + (r < 8 ? 8 * j8 + r : 64 + 8 * j8 + (r - 8));
+    } else {
+        row = min(tile * 16 + r, N - 1);
+    }
+    *(bf16x8*)(dst + (blk * 64 + lane) * 8) = *(const bf16x8*)(W + (int64_t)row * ldw + ks * 32 + (lane >> 4) * 8);
 }
 
 int env_int(const char* name, int dflt) {
@@ -251,6 +282,17 @@ int launch_decode_gemm(int which, const DecodeGemmParams& p, hipStream_t st) {
     DecodeGemmParams q = p;
     if (dflags >= 0) q.flags = dflags;
     return launch_decode_gemm_(which, q, st);
+}
+
+size_t decode_swizzled_bytes(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K * 2; }
+
+int decode_swizzle_weight(int which, const bf16* W, int64_t ldw, int N, int K, bf16* dst, hipStream_t st) {
+    if (!W || !dst || N <= 0 || K <= 0 || (K & 31) || (ldw & 7) || (which == DEC_WQKV && (N % HD))) return CR_ERR_ARG;
+    const int64_t blocks = (int64_t)((N + 15) / 16) * (K / 32);
+    const unsigned grid = (unsigned)((blocks + 3) / 4);
+    if (which == DEC_WQKV) hipLaunchKernelGGL(decode_swizzle_kernel<true>, dim3(grid), dim3(256), 0, st, W, ldw, N, K, dst);
+    else hipLaunchKernelGGL(decode_swizzle_kernel<false>, dim3(grid), dim3(256), 0, st, W, ldw, N, K, dst);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
 static int launch_decode_gemm_(int which, const DecodeGemmParams& p, hipStream_t st) {

@@ -296,7 +296,8 @@ int gemm8(cr_ctx* c, int epi, const bf16* A, int64_t lda, const DevTensor* w8, c
     return ctx_gemm(c, epi, p, st);
 }
 
-struct LayerW { const bf16 *an, *fn, *wqkv, *wo, *w13, *w2; const DevTensor *q_qkv, *s_qkv, *q_o, *s_o, *q_13, *s_13, *q_2, *s_2; };
+struct LayerW { const bf16 *an, *fn, *wqkv, *wo, *w13, *w2; const DevTensor *d_qkv, *d_o, *d_13, *d_2;      // d_*: decode-layout copies (llm_finalize), may be null
+                const DevTensor *q_qkv, *s_qkv, *q_o, *s_o, *q_13, *s_13, *q_2, *s_2; };
 
 const DevTensor* opt(cr_ctx* c, const std::string& name) {
     auto it = c->w.find(name);
@@ -308,6 +309,8 @@ int layer_weights(cr_ctx* c, int l, LayerW& w) {
     w.an = W(c, p + "attention_norm.weight"); w.fn = W(c, p + "ffn_norm.weight");
     w.wqkv = W(c, p + "attention.wqkv.weight"); w.wo = W(c, p + "attention.wo.weight");
     w.w13 = W(c, "derived.w13." + std::to_string(l)); w.w2 = W(c, p + "feed_forward.w2.weight");
+    w.d_qkv = opt(c, "declayout." + p + "attention.wqkv.weight"); w.d_o = opt(c, "declayout." + p + "attention.wo.weight");
+    w.d_13 = opt(c, "declayout.derived.w13." + std::to_string(l)); w.d_2 = opt(c, "declayout." + p + "feed_forward.w2.weight");
     w.q_qkv = opt(c, "fp8." + p + "attention.wqkv.weight"); w.s_qkv = opt(c, "fp8s." + p + "attention.wqkv.weight");
     w.q_o = opt(c, "fp8." + p + "attention.wo.weight"); w.s_o = opt(c, "fp8s." + p + "attention.wo.weight");
     w.q_13 = opt(c, "fp8.derived.w13." + std::to_string(l)); w.s_13 = opt(c, "fp8s.derived.w13." + std::to_string(l));
@@ -363,6 +366,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             DecodeGemmParams dp{};
             dp.M = M; dp.eps = c->d.rms_eps;
             dp.W = w.wqkv; dp.ldw = D; dp.N = QKV; dp.K = D; dp.xres = x; dp.gamma = w.an;
+            if (w.d_qkv) { dp.W = (const bf16*)w.d_qkv->ptr; dp.swizzled = 1; }
             dp.cosT = cosT; dp.sinT = sinT; dp.q_out = q; dp.kc = kc; dp.vc = vc; dp.seqs = d_seqs; dp.lens = kv->d_len; dp.max_tokens = kv->max_tokens;
             CR_TRY(launch_decode_gemm(DEC_WQKV, dp, st));
             AttnParams ap{};
@@ -377,14 +381,17 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             DecodeGemmParams dq{};
             dq.M = M; dq.eps = c->d.rms_eps;
             dq.W = w.wo; dq.ldw = D; dq.N = D; dq.K = D; dq.X = ao; dq.ldx = D; dq.xio = x;
+            if (w.d_o) { dq.W = (const bf16*)w.d_o->ptr; dq.swizzled = 1; }
             CR_TRY(launch_decode_gemm(DEC_WO, dq, st));
             dq = DecodeGemmParams{};
             dq.M = M; dq.eps = c->d.rms_eps;
             dq.W = w.w13; dq.ldw = D; dq.N = 2 * ff; dq.K = D; dq.xres = x; dq.gamma = w.fn; dq.C = act; dq.ldc = ff;
+            if (w.d_13) { dq.W = (const bf16*)w.d_13->ptr; dq.swizzled = 1; }
             CR_TRY(launch_decode_gemm(DEC_W13, dq, st));
             dq = DecodeGemmParams{};
             dq.M = M; dq.eps = c->d.rms_eps;
             dq.W = w.w2; dq.ldw = ff; dq.N = D; dq.K = ff; dq.X = act; dq.ldx = ff; dq.xio = x;
+            if (w.d_2) { dq.W = (const bf16*)w.d_2->ptr; dq.swizzled = 1; }
             CR_TRY(launch_decode_gemm(DEC_W2, dq, st));
             continue;
         }
@@ -523,6 +530,40 @@ int llm_finalize(cr_ctx* c, hipStream_t st) {
         hipFree(i1->second.ptr); hipFree(i3->second.ptr);      // the interleaved copy replaces them
         c->w.erase(i1); c->w.erase(c->w.find(p + "w3.weight"));
         c->w[dn] = t;
+    }
+    // Decode-layout copies of the five weight streams of a small-batch decode step (gemm_decode.hip: one contiguous KiB per load instruction instead of
+    // 16 rows x 64 bytes; wqkv 16.7 -> 11.1 us, w1|w3 43.1 -> 37.5, w2 26.0 -> 20.5, LM head 130 -> 116 at one row, the same bits): +15.9 GB on
+    // InternLM2.5-7B, taken from the 288 GB only if the shapes are the ones the kernels are built for.  CR_DECODE_LAYOUT=0: none (A/B aid); a failed allocation
+    // leaves the decode path on the nn.Linear layout.
+    {
+        for (auto it = c->w.begin(); it != c->w.end();) {         // copies of an earlier cr_finalize: the weights may have been reloaded
+            if (it->first.rfind("declayout.", 0) == 0) { hipFree(it->second.ptr); it = c->w.erase(it); } else ++it;
+        }
+        const char* e = getenv("CR_DECODE_LAYOUT");
+        const DevTensor* w13_0 = WT(c, "derived.w13.0");
+        const bool want = c->fused_decode && !(e && atoi(e) == 0) && w13_0 && decode_fused_supported(1, (int)w13_0->shape[0] / 2);
+        auto derive = [&](int which, const std::string& nm, int64_t N, int64_t K) -> bool {
+            const DevTensor* src = WT(c, nm);
+            if (!src || src->shape.size() != 2 || src->shape[0] != N || src->shape[1] != K) return false;
+            DevTensor t;
+            t.dtype = CR_BF16; t.shape = {(N + 15) / 16 * 16, K}; t.bytes = decode_swizzled_bytes((int)N, (int)K);
+            if (hipMalloc(&t.ptr, t.bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (decode_swizzle_weight(which, (const bf16*)src->ptr, K, (int)N, (int)K, (bf16*)t.ptr, st) != CR_OK) { hipFree(t.ptr); return false; }
+            c->w["declayout." + nm] = t;
+            return true;
+        };
+        bool ok = want;
+        for (int l = 0; ok && l < c->d.llm_layers; l++) {
+            const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
+            const int64_t ff = w13_0->shape[0] / 2;
+            ok = derive(DEC_WQKV, p + "attention.wqkv.weight", QKV, D) && derive(DEC_WO, p + "attention.wo.weight", D, D) &&
+                 derive(DEC_W13, "derived.w13." + std::to_string(l), 2 * ff, D) && derive(DEC_W2, p + "feed_forward.w2.weight", D, ff);
+        }
+        if (ok) {
+            const DevTensor* ow = WT(c, "language_model.output.weight");
+            if (ow && ow->shape.size() == 2 && ow->shape[1] == D) derive(DEC_HEAD, "language_model.output.weight", ow->shape[0], D);
+        }
+        CR_HIP(hipStreamSynchronize(st));
     }
     return CR_OK;
 }
@@ -798,6 +839,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
         if (c->fused_decode && !c->fp8_decode && !c->no_sliced_decode && decode_fused_supported(n, ff_)) {
             DecodeGemmParams dh{};                                // final RMSNorm folded into the LM head (gemm_decode.hip)
             dh.M = n; dh.eps = c->d.rms_eps; dh.W = ow; dh.ldw = D; dh.N = V; dh.K = D; dh.xres = x; dh.gamma = nw; dh.C = lg; dh.ldc = V;
+            if (const DevTensor* dl = opt(c, "declayout.language_model.output.weight")) { dh.W = (const bf16*)dl->ptr; dh.swizzled = 1; }
             CR_TRY(launch_decode_gemm(DEC_HEAD, dh, st));
         } else {
         CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));

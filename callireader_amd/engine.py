@@ -368,12 +368,23 @@ def op_attention(q, k, v, o, strides, Bn, H, Sq, Sk, head_dim, kv_group=1, causa
     return o
 
 
-def op_decode_gemm(which, W, M, X=None, xres=None, gamma=None, eps=1e-5, xio=None, C_out=None, rope=None, flags=0):
+def op_decode_swizzle(which, W):
+    """cr_op_decode_swizzle: the decode layout of a [N, K] weight for op_decode_gemm's `which` (1 KiB per 16-row tile and 32-deep k-step)."""
+    N, K = W.shape
+    out = torch.empty(((N + 15) // 16) * 16 * K, dtype=torch.bfloat16, device=W.device)
+    B.check(B.lib.cr_op_decode_swizzle(which, _p(W), W.stride(0), N, K, _p(out), _stream()), 'cr_op_decode_swizzle')
+    return out
+
+
+def op_decode_gemm(which, W, M, X=None, xres=None, gamma=None, eps=1e-5, xio=None, C_out=None, rope=None, flags=0, swizzled=None):
     """cr_op_decode_gemm: one small-batch decode GEMM with its neighbours folded in (gemm_decode.hip).  which: 0 wqkv (rope = dict with
-    cos, sin, q_out, kc, vc, seqs, lens, max_tokens), 1 wo, 2 w1|w3, 3 w2, 4 LM head."""
+    cos, sin, q_out, kc, vc, seqs, lens, max_tokens), 1 wo, 2 w1|w3, 3 w2, 4 LM head.  swizzled: op_decode_swizzle(which, W) -- the kernel then
+    streams that copy (W still gives N and K)."""
     N, K = W.shape
     r = rope or {}
-    B.check(B.lib.cr_op_decode_gemm(which, flags, _p(W), K, M, N, K, _p(X), X.shape[1] if X is not None else 0, _p(xres), _p(gamma), eps, _p(xio),
+    Wp = W if swizzled is None else swizzled
+    B.check(B.lib.cr_op_decode_gemm(which, flags | (256 if swizzled is not None else 0), _p(Wp), K, M, N, K, _p(X), X.shape[1] if X is not None else 0,
+                                    _p(xres), _p(gamma), eps, _p(xio),
                                     _p(C_out), C_out.shape[1] if C_out is not None else 0, _p(r.get('cos')), _p(r.get('sin')), _p(r.get('q_out')),
                                     _p(r.get('kc')), _p(r.get('vc')), _p(r.get('seqs')), _p(r.get('lens')), r.get('max_tokens', 0), _stream()),
             'cr_op_decode_gemm')

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 7   /* 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 8   /* 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -233,10 +233,15 @@ int cr_op_gemm_q8(const void* a8, const float* ascale, const void* w8, const flo
  * [RMSNorm(xres) -> GEMM -> RoPE + split: q_out rows, K / V rows into kc / vc at (seqs[m], lens[seqs[m]])], 1 wo [X -> GEMM -> xio += ],
  * 2 w1|w3 [RMSNorm(xres) -> GEMM -> SwiGLU -> C], 3 w2 [as 1], 4 LM head [RMSNorm(xres) -> GEMM -> fp32 C].  Replaces, per decode step of
  * InternLM2DecoderLayer.forward (modeling_internlm2.py:621-681): the norm / linear / rotary / residual statements around each linear.
- * Test and tuning entry point (cr_llm_decode drives the same launcher).  flags: 0 (reserved for tuning knobs). */
+ * Test and tuning entry point (cr_llm_decode drives the same launcher).  flags: bit 8 (256) = W is in the decode layout cr_op_decode_swizzle
+ * writes (ldw ignored); other bits 0. */
 int cr_op_decode_gemm(int which, int flags, const void* W, int64_t ldw, int M, int N, int K, const void* X, int64_t ldx, const void* xres,
                       const void* gamma, float eps, void* xio, void* C, int64_t ldc, const void* cosT, const void* sinT, void* q_out, void* kc,
                       void* vc, const int32_t* seqs, const int32_t* lens, int max_tokens, void* stream);
+/* The decode layout of a weight for cr_op_decode_gemm's `which`: one 1 KiB block per (16-row tile, 32-deep k-step), lane l's eight elements at l * 16
+ * bytes, in the kernel's own tile order (which = 0: RoPE tiles of 8 + 8 rows) -- a wave's load is one contiguous KiB instead of 16 rows x 64 bytes.
+ * dst: ceil(N / 16) * 16 * K bf16.  cr_finalize keeps such a copy of every LLM linear (+15 GB on InternLM2.5-7B) for decode batches of <= 8 rows. */
+int cr_op_decode_swizzle(int which, const void* W, int64_t ldw, int N, int K, void* dst, void* stream);
 /* q/k/v/o addressed as base + b*bs + row*rs + head*hs (elements) */
 int cr_op_attention(const void* q, const void* k, const void* v, void* o, const int64_t* strides12, int B, int H,
                     int Sq, int Sk, int head_dim, int kv_group, int causal, int q_pos0, float q_prescale, float s_div,

@@ -67,13 +67,26 @@ for M in ROWS:
     torch.cuda.synchronize()
     print(f'rows {M}: max |d| wo {e1:.3g}, w13 (rel) {e2:.3g}, head {e4:.3g}, wqkv V rows {e0:.3g}')
     res = {}
-    for flags in (0,):
+    SWZ = {nm: [E.op_decode_swizzle(wh, w) for w in W[nm]] for nm, wh in (('wqkv', 0), ('wo', 1), ('w13', 2), ('w2', 3), ('head', 4))}
+    # same bits from the decode layout?
+    xa, xb = x.clone(), x.clone()
+    E.op_decode_gemm(3, W['w2'][0], M, X=act, xio=xa); E.op_decode_gemm(3, W['w2'][0], M, X=act, xio=xb, swizzled=SWZ['w2'][0])
+    la, lb = torch.zeros_like(logits), torch.zeros_like(logits)
+    E.op_decode_gemm(4, W['head'][0], M, xres=x, gamma=gm, C_out=la); E.op_decode_gemm(4, W['head'][0], M, xres=x, gamma=gm, C_out=lb, swizzled=SWZ['head'][0])
+    qa = dict(rope, q_out=torch.zeros_like(rope['q_out']), kc=torch.zeros_like(rope['kc']), vc=torch.zeros_like(rope['vc']))
+    qb = dict(rope, q_out=torch.zeros_like(rope['q_out']), kc=torch.zeros_like(rope['kc']), vc=torch.zeros_like(rope['vc']))
+    E.op_decode_gemm(0, W['wqkv'][0], M, xres=x, gamma=gm, rope=qa); E.op_decode_gemm(0, W['wqkv'][0], M, xres=x, gamma=gm, rope=qb, swizzled=SWZ['wqkv'][0])
+    torch.cuda.synchronize()
+    print('   decode layout gives the same bits:', bool(torch.equal(xa, xb) and torch.equal(la, lb) and torch.equal(qa['q_out'], qb['q_out']) and torch.equal(qa['kc'], qb['kc']) and torch.equal(qa['vc'], qb['vc'])))
+    for variant in (0, 1):                                   # 0: weights as nn.Linear stores them, 1: the decode layout
+        sw = (lambda nm, i: SWZ[nm][i % len(SWZ[nm])]) if variant else (lambda nm, i: None)
+        flags = 0
         xs = x.clone()
-        res[('wqkv', flags)] = timeit(lambda i: E.op_decode_gemm(0, W['wqkv'][i % len(W['wqkv'])], M, xres=x, gamma=gm, rope=rope, flags=flags), len(W['wqkv']) * 3)
-        res[('wo', flags)] = timeit(lambda i: E.op_decode_gemm(1, W['wo'][i % len(W['wo'])], M, X=ao, xio=xs, flags=flags), len(W['wo']) * 3)
-        res[('w13', flags)] = timeit(lambda i: E.op_decode_gemm(2, W['w13'][i % len(W['w13'])], M, xres=x, gamma=gm, C_out=act_out, flags=flags), len(W['w13']) * 3)
-        res[('w2', flags)] = timeit(lambda i: E.op_decode_gemm(3, W['w2'][i % len(W['w2'])], M, X=act, xio=xs, flags=flags), len(W['w2']) * 3)
-        res[('head', flags)] = timeit(lambda i: E.op_decode_gemm(4, W['head'][i % len(W['head'])], M, xres=x, gamma=gm, C_out=logits, flags=flags), len(W['head']) * 2)
+        res[('wqkv', variant)] = timeit(lambda i: E.op_decode_gemm(0, W['wqkv'][i % len(W['wqkv'])], M, xres=x, gamma=gm, rope=rope, flags=flags, swizzled=sw('wqkv', i)), len(W['wqkv']) * 3)
+        res[('wo', variant)] = timeit(lambda i: E.op_decode_gemm(1, W['wo'][i % len(W['wo'])], M, X=ao, xio=xs, flags=flags, swizzled=sw('wo', i)), len(W['wo']) * 3)
+        res[('w13', variant)] = timeit(lambda i: E.op_decode_gemm(2, W['w13'][i % len(W['w13'])], M, xres=x, gamma=gm, C_out=act_out, flags=flags, swizzled=sw('w13', i)), len(W['w13']) * 3)
+        res[('w2', variant)] = timeit(lambda i: E.op_decode_gemm(3, W['w2'][i % len(W['w2'])], M, X=act, xio=xs, flags=flags, swizzled=sw('w2', i)), len(W['w2']) * 3)
+        res[('head', variant)] = timeit(lambda i: E.op_decode_gemm(4, W['head'][i % len(W['head'])], M, xres=x, gamma=gm, C_out=logits, flags=flags, swizzled=sw('head', i)), len(W['head']) * 2)
     # the separate kernels these replace, as far as single ops exist: the K-sliced partial GEMMs / streaming GEMMs alone (no norm, RoPE or add kernel)
     old = {}
     hb = h.bfloat16()
@@ -86,7 +99,5 @@ for M in ROWS:
     mb = {'wqkv': QKV * D * 2e-6, 'wo': D * D * 2e-6, 'w13': 2 * FF * D * 2e-6, 'w2': D * FF * 2e-6, 'head': V * D * 2e-6}
     for k in ('wqkv', 'wo', 'w13', 'w2', 'head'):
         line = f'  {k:5s} {mb[k]:6.1f} MB: separate GEMM alone {old[k]:7.2f} us ({mb[k] / old[k]:.2f} TB/s) | fused'
-        for flags in (0,):
-            line += f'  f{flags} {res[(k, flags)]:7.2f}'
-        line += f'  ({mb[k] / min(res[(k, f)] for f in (0,)):.2f} TB/s)'
+        line += f' {res[(k, 0)]:7.2f} ({mb[k] / res[(k, 0)]:.2f} TB/s) | fused, decode layout {res[(k, 1)]:7.2f} ({mb[k] / res[(k, 1)]:.2f} TB/s)'
         print(line, flush=True)

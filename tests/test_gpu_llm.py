@@ -187,6 +187,48 @@ def test_fused_small_batch_decode_gives_the_separate_kernels_bits(setup, rows):
     ref.close()
 
 
+@pytest.mark.parametrize('rows', [1, 5, 8])
+def test_decode_layout_of_the_weights_gives_the_same_bits(rows):
+    """cr_finalize keeps a second copy of every LLM linear in the decode layout (one contiguous KiB per 16-row tile and 32-deep k-step, wqkv in
+    its RoPE tile order; cr_op_decode_swizzle) and the small-batch decode GEMMs stream that copy: the same values reach the same registers, so
+    every output must be the same bits as from the nn.Linear layout -- all five GEMMs, a vocabulary that is not a multiple of 16."""
+    from callireader_amd import engine as E
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(rows)
+    D, FF, V, QKV = 4096, 14336, 8201, 6144
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).bfloat16()
+    x, ao, act = rnd(rows, D), rnd(rows, D, sc=0.5), rnd(rows, FF, sc=0.5)
+    gm = (1 + 0.1 * torch.randn(D, device=dev, generator=g)).bfloat16()
+    W = {0: rnd(QKV, D, sc=0.02), 1: rnd(D, D, sc=0.02), 2: rnd(2 * FF, D, sc=0.02), 3: rnd(D, FF, sc=0.02), 4: rnd(V, D, sc=0.02)}
+    S = {k: E.op_decode_swizzle(k, w) for k, w in W.items()}
+    assert S[4].numel() == ((V + 15) // 16) * 16 * D
+    max_tokens = 64
+
+    def rope():
+        return dict(cos=rope_c, sin=rope_s, q_out=torch.zeros(rows, D, device=dev, dtype=torch.bfloat16),
+                    kc=torch.zeros(rows, 8, max_tokens, 128, device=dev, dtype=torch.bfloat16), vc=torch.zeros(rows, 8, max_tokens, 128, device=dev, dtype=torch.bfloat16),
+                    seqs=torch.arange(rows, device=dev, dtype=torch.int32), lens=torch.full((rows,), 9, device=dev, dtype=torch.int32), max_tokens=max_tokens)
+    rope_c, rope_s = rnd(max_tokens, 128), rnd(max_tokens, 128)
+    outs = []
+    for sw in (False, True):
+        pick = lambda k: S[k] if sw else None
+        r = rope()
+        E.op_decode_gemm(0, W[0], rows, xres=x, gamma=gm, rope=r, swizzled=pick(0))
+        xa = x.clone()
+        E.op_decode_gemm(1, W[1], rows, X=ao, xio=xa, swizzled=pick(1))
+        a13 = torch.zeros(rows, FF, device=dev, dtype=torch.bfloat16)
+        E.op_decode_gemm(2, W[2], rows, xres=x, gamma=gm, C_out=a13, swizzled=pick(2))
+        xb = x.clone()
+        E.op_decode_gemm(3, W[3], rows, X=act, xio=xb, swizzled=pick(3))
+        lg = torch.zeros(rows, V, device=dev, dtype=torch.float32)
+        E.op_decode_gemm(4, W[4], rows, xres=x, gamma=gm, C_out=lg, swizzled=pick(4))
+        torch.cuda.synchronize()
+        outs.append((r['q_out'], r['kc'], r['vc'], xa, a13, xb, lg))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][6].abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
+
+
 def test_decode_graph_replay_equals_plain_launches(setup):
     """CR_DECODE_GRAPH=1 (opt-in): the decode step captured as a hipGraph and replayed -- across a change of the number
     of attention splits (a second capture) and with prefills in between -- generates exactly the plain path's ids."""
