@@ -240,6 +240,7 @@ int cr_op_gemm(int epi, const void* A, int64_t lda, const void* Wt, int64_t ldw,
     p.slots = kern == 5 ? 16 : kern == 6 ? 32 : 0;            // 5 / 6: the 256x256 kernel with its 16- / 32-MFMA-slot schedule pinned
     if (epi & (1 << 16)) { p.w8 = 1; p.wscale = (const float*)scale; p.scale = nullptr; }      // e4m3 weights + per-row fp32 scales
     if (epi & (1 << 17)) { p.a8 = 1; p.ascale = (const float*)res; p.res = nullptr; }          // e4m3 activations too: `res` = fp32 row scales [M]
+    p.wsw = (epi >> 18) & 3;                      // weights in the decode layout (cr_op_decode_swizzle): 1 plain tiles, 2 wqkv's RoPE tile order
     epi &= 0xff;
     int r = launch_gemm(epi, p, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_gemm(epi=%d, M=%d, N=%d, K=%d) rejected or failed to launch", epi, M, N, K);

@@ -173,7 +173,13 @@ struct GemmParams {
     int a8;
     const float* ascale;
     const float* c8scale;      // EPI_GELU_Q8: C is e4m3 bytes [M][ldc], row m divided by c8scale[m] (an upper bound of the row's magnitude / 448)
+    // decode layout (M <= 64, bf16 weights, the weight-streaming kernels only): W points at decode_swizzle_weight's copy -- one contiguous KiB per 16-row tile
+    // and 32-deep k-step, lane l's 16 bytes at l * 16 (ldw unused).  1: tiles are rows 16 t .. 16 t + 15; 2: wqkv's RoPE tile order (8 rows of a head's
+    // first half + the 8 rows 64 further on; EPI_PARTIAL only: the sums land in their nn.Linear columns).  N % 16 == 0 except for layout 1's last tile.
+    int wsw;
 };
+// row of W that tile t, row r of the RoPE tile order holds (gemm_decode.hip: wrow; head dim 128)
+__host__ __device__ __forceinline__ int rope_tile_row(int t, int r) { return (t >> 3) * 128 + (r < 8 ? 8 * (t & 7) + r : 64 + 8 * (t & 7) + (r - 8)); }
 
 // EPI_ARGMAX partial of one row and one 64-column block: the bf16-rounded maximum (as fp32 bits, high word) and its column
 // (low word); -inf / column 0x7fffffff for a block with no valid column.  Merging takes the larger value, then the

@@ -52,8 +52,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
     const int ksteps = p.K / (32 * WAVES * (int)gridDim.y);            // k-steps of 32 per wave
     const int kbase = ((int)blockIdx.y * WAVES + wave) * ksteps * 32;
     const bf16* wp[RT];
+    // decode layout (p.wsw): tile (n0 / 16 + r), k-step kbase / 32 onwards, one KiB per k-step, this lane's 16 bytes at lane * 16
+    const int wstep = (!W8 && p.wsw) ? 512 : 32;                  // elements between a lane's loads of consecutive k-steps
 #pragma unroll
-    for (int r = 0; r < RT; r++) wp[r] = p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq;
+    for (int r = 0; r < RT; r++)
+        wp[r] = (!W8 && p.wsw) ? p.W + ((int64_t)min(n0 / 16 + r, (p.N + 15) / 16 - 1) * (p.K / 32) + kbase / 32) * 512 + lane * 8
+                               : p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq;
     const bf16* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) xp[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
 #pragma unroll
         for (int r = 0; r < RT; r++)
 #pragma unroll
-            for (int u = 0; u < UR; u++) w[r][u] = __builtin_nontemporal_load((const bf16x8*)(wp[r] + (ks + u) * 32));
+            for (int u = 0; u < UR; u++) w[r][u] = __builtin_nontemporal_load((const bf16x8*)(wp[r] + (ks + u) * wstep));
 #pragma unroll
         for (int t = 0; t < MT; t++)
 #pragma unroll
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         for (int t = 0; t < MT; t++) x[t] = *(const bf16x8*)(xp[t] + ks * 32);
 #pragma unroll
         for (int r = 0; r < RT; r++) {
-            const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp[r] + ks * 32));
+            const bf16x8 w = __builtin_nontemporal_load((const bf16x8*)(wp[r] + ks * wstep));
 #pragma unroll
             for (int t = 0; t < MT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x[t], acc[r][t], 0, 0, 0);
         }
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         float* out = (float*)p.C + (int64_t)blockIdx.y * p.M * p.ldc;
         for (int idx = tid; idx < RT * MT * 256; idx += WAVES * 64) {
             const int t = idx >> 8, n = idx & 15, m = (idx >> 4) & 15;
-            const int gm = (t % MT) * 16 + m, gn = n0 + (t / MT) * 16 + n;
+            const int gm = (t % MT) * 16 + m, gn = p.wsw == 2 ? rope_tile_row(n0 / 16 + t / MT, n) : n0 + (t / MT) * 16 + n;
             if (gm < p.M && gn < p.N) out[(int64_t)gm * p.ldc + gn] = red[0][t][n][m];
         }
         return;

@@ -38,7 +38,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     const int k0 = split * ks_len;
     const int chunks = ks_len / (32 * KSC);
 
-    const bf16* wp = p.W + (int64_t)min(n0 + (lane & 15), p.N - 1) * p.ldw + k0 + (lane >> 4) * 8;
+    // decode layout (p.wsw == 1): this wave's tile is one contiguous run of KiB blocks, a chunk = 16 KiB
+    const int wstep = p.wsw ? 512 : 32;
+    const bf16* wp = p.wsw ? p.W + ((int64_t)min(n0 / 16, (p.N + 15) / 16 - 1) * (p.K / 32) + k0 / 32) * 512 + lane * 8
+                           : p.W + (int64_t)min(n0 + (lane & 15), p.N - 1) * p.ldw + k0 + (lane >> 4) * 8;
     // X staging: sub-tile s = (row tile s >> 3, k-step s & 7); wave w brings s = w, w + NW, ...; lane -> row lane >> 2 of the
     // sub-tile, 16-byte chunk (lane & 3) ^ 2 (row >> 3) (the image gemm256.hip reads without bank conflicts)
     const int srow = lane >> 2, schunk = (lane & 3) ^ ((srow >> 3) << 1);
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     bf16x8 wa[KSC], wb[KSC];
     auto loadw = [&](bf16x8* w, int c) {
 #pragma unroll
-        for (int ks = 0; ks < KSC; ks++) w[ks] = __builtin_nontemporal_load((const bf16x8*)(wp + c * (32 * KSC) + ks * 32));
+        for (int ks = 0; ks < KSC; ks++) w[ks] = __builtin_nontemporal_load((const bf16x8*)(wp + (c * KSC + ks) * wstep));
     };
     f32x4 tot[MT];
 #pragma unroll
@@ -193,8 +196,8 @@ int gemm_stream_waves(int N, int splits) {
 
 bool gemm_stream_supported(int epi, const GemmParams& p, int splits) {
     // exactly the launches gemm_skinny.hip would run with FOUR waves over K and whose quarters are whole 256-deep chunks
-    if (p.w8 || p.a8 || p.M <= 16 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0) return false;
-    if ((p.lda & 7) || (p.ldw & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+    if (p.w8 || p.a8 || p.M <= 16 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
+    if ((p.lda & 7) || (!p.wsw && (p.ldw & 7)) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;
     if (epi == EPI_SWIGLU) return p.N % 16 == 0 && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 7) == 0;

@@ -271,9 +271,11 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const bf16* __restric
 }
 
 int gemm(cr_ctx* c, int epi, const bf16* A, int64_t lda, const bf16* Wt, int64_t ldw, void* C, int64_t ldc, const bf16* res, int64_t ldr,
-         int M, int N, int K, hipStream_t st, bool prefill_rows = false) {
+         int M, int N, int K, hipStream_t st, bool prefill_rows = false, const DevTensor* dl = nullptr, int dl_kind = 1) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.res = res; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
+    // decode (<= 64 rows): the weight-streaming kernels take the decode-layout copy where llm_finalize made one (a contiguous KiB per load instruction)
+    if (dl && !prefill_rows && M <= 64) { p.W = (const bf16*)dl->ptr; p.wsw = dl_kind; }
     // a prompt row's result must not depend on what it is prefilled with: prompts of <= 64 rows in all stay on the tiled kernel, whose K
     // order is that of every longer prefill (the weight-streaming kernel the dispatcher would pick splits K over its waves)
     if (prefill_rows && M <= 64) p.kernel = 128;
@@ -401,7 +403,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         const bool f8 = decode && M <= 64 && c->fp8_decode && w.q_qkv && w.s_qkv && w.q_o && w.s_o && w.q_13 && w.s_13 && w.q_2 && w.s_2;
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_STORE, h, hs, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, M, QKV, D, st));
         else if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st)
-                               : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st));
+                               : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st, false, w.d_qkv, 2));
         else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st)
                         : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st, !decode));
         hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
@@ -430,7 +432,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         }
         if (sliced) {
             CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, ao, D, w.q_o, w.s_o, pbuf, D, nullptr, 0, M, D, D, st)
-                      : gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st));
+                      : gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st, false, w.d_o));
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_o, M, w.fn, h, c->d.rms_eps, st));
         } else {
             if (m8all) {    // wo and w2 take activations no norm produced: one quantiser pass each (row maximum, then the e4m3 row)
@@ -444,10 +446,10 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         }
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_SWIGLU, h, hs, w.q_13, w.s_13, act, ff, nullptr, M, 2 * ff, D, st));
         else CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st)
-                       : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st, !decode));
+                       : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st, !decode, decode ? w.d_13 : nullptr));
         if (sliced) {
             CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, act, ff, w.q_2, w.s_2, pbuf, D, nullptr, 0, M, D, ff, st)
-                      : gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st));
+                      : gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st, false, w.d_2));
             const bf16* next_norm = nullptr;             // the last layer's sum only lands in x: the caller norms what it needs
             if (l + 1 < c->d.llm_layers) {
                 LayerW wn;
@@ -541,7 +543,7 @@ int llm_finalize(cr_ctx* c, hipStream_t st) {
         }
         const char* e = getenv("CR_DECODE_LAYOUT");
         const DevTensor* w13_0 = WT(c, "derived.w13.0");
-        const bool want = c->fused_decode && !(e && atoi(e) == 0) && w13_0 && decode_fused_supported(1, (int)w13_0->shape[0] / 2);
+        const bool want = !(e && atoi(e) == 0) && w13_0 && decode_fused_supported(1, (int)w13_0->shape[0] / 2);
         auto derive = [&](int which, const std::string& nm, int64_t N, int64_t K) -> bool {
             const DevTensor* src = WT(c, nm);
             if (!src || src->shape.size() != 2 || src->shape[0] != N || src->shape[1] != K) return false;
@@ -844,7 +846,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
         } else {
         CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
         if (c->fp8_decode && n <= 64 && q_out && s_out) CR_TRY(gemm8(c, EPI_F32, hl, D, q_out, s_out, lg, V, nullptr, 0, n, V, D, st));
-        else CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st));
+        else CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st, false, opt(c, "declayout.language_model.output.weight")));
         }
         if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(pick_kernel, dim3(n), dim3(1024), 0, st, lg, (int64_t)V, V, penalty, 0, kv->d_seqs, kv->d_gen, kv->d_ngen,

@@ -271,11 +271,16 @@ class KVCache:
 
 
 # ---- single operators (tests / profiling) ----
-def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None, kernel=0, out=None):
+def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torch.bfloat16, n_out=None, kernel=0, out=None, decode_layout=None):
     """kernel: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent (schedule per shape), 3 weight-streaming, 5 / 6 the 256x256 kernel with
-    its 16- / 32-MFMA-slot schedule pinned (tests pin one)."""
+    its 16- / 32-MFMA-slot schedule pinned (tests pin one).  decode_layout = (kind, op_decode_swizzle(which, Wt)): the weight-streaming kernels
+    (M <= 64) read that copy of the weight (kind 1: plain tiles, 2: wqkv's RoPE tile order with epi 7); Wt still gives N."""
     M, K = A.shape
     N = Wt.shape[0]
+    hi = 0
+    if decode_layout is not None:
+        hi = decode_layout[0] << 18
+        Wt = decode_layout[1].view(-1, K)
     ncols = n_out if n_out is not None else (N // 2 if epi == 4 else N)
     mrows = M if epi != 5 else (M // group) * (group + 1)
     if epi == 7:                     # fp32 K-slice partial sums [S <= 8][M][N]; unused slabs stay zero
@@ -283,7 +288,7 @@ def op_gemm(epi, A, Wt, bias=None, scale=None, res=None, group=0, out_dtype=torc
     if epi == 8:                     # cosine-VQ partials: per row and 64-column block {column (low word), bits of the bf16 max (high word)}
         ncols, out_dtype = ((N + 63) // 64 + 1) & ~1, torch.int64
     Cc = out if out is not None else torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
-    B.check(B.lib.cr_op_gemm(epi | (kernel << 8), _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
+    B.check(B.lib.cr_op_gemm(epi | (kernel << 8) | hi, _p(A), A.stride(0), _p(Wt), Wt.stride(0), _p(Cc), Cc.stride(0), _p(bias), _p(scale),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, group, _stream()), 'cr_op_gemm')
     return Cc
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 8   /* 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 8   /* 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8, cr_op_gemm bits 18-19; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -207,7 +207,10 @@ int cr_orderformer(cr_ctx* ctx, const void* boxes, int B, int L, float* scores, 
  *   high word, its first column in the low word; M > 64 tile kernels only).
  * Bits 8..15 of epi pin a kernel for the unit tests: 0 dispatcher's choice, 1 128x128 tiles, 2 256x256 persistent,
  * 3 weight-streaming (M <= 64), 5 / 6 the 256x256 kernel with its 16- / 32-MFMA-slot schedule (the same sums: the same bits);
- * a pinned kernel that cannot take the shape returns CR_ERR_ARG. */
+ * a pinned kernel that cannot take the shape returns CR_ERR_ARG.
+ * Bits 18-19 (M <= 64, bf16 weights, the weight-streaming kernels): W is cr_op_decode_swizzle's copy of the weight (ldw ignored) -- 1: plain 16-row
+ * tiles (its which = 1..4), 2: wqkv's RoPE tile order (which = 0; epi 7 only: the K-slices still land in their nn.Linear columns).  The same bits as
+ * from the nn.Linear layout. */
 int cr_op_gemm(int epi, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                const void* bias, const void* scale, const void* res, int64_t ldr, int M, int N, int K, int group,
                void* stream);

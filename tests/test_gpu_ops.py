@@ -663,3 +663,22 @@ def test_gemm256_launches_back_to_back_are_identical(E, epi):
         torch.cuda.synchronize()
         for o in outs:
             assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize('M', [9, 16, 33, 64])
+def test_weight_streaming_gemms_take_the_decode_layout_with_the_same_bits(E, M):
+    """The decode GEMMs of 9..64 rows (K-sliced partial sums for wqkv / wo / w2, SwiGLU for w1|w3, fp32 logits with a ragged vocabulary) read the
+    decode-layout copy of their weight (cr_op_decode_swizzle: a contiguous KiB per load instruction; wqkv in its RoPE tile order, the sums still
+    landing in their nn.Linear columns): every output is the same bits as from the nn.Linear layout."""
+    g = torch.Generator().manual_seed(M)
+    D, FF, V, QKV = 4096, 14336, 8201, 6144
+    def w(n, k): return bf(_rand((n, k), g, 0.02)).to(dev())
+    x, act = bf(_rand((M, D), g)).to(dev()), bf(_rand((M, FF), g, 0.5)).to(dev())
+    for which, epi, A, W, kind in ((0, 7, x, w(QKV, D), 2), (1, 7, x, w(D, D), 1), (2, 4, x, w(2 * FF, D), 1), (3, 7, act, w(D, FF), 1), (4, 6, x, w(V, D), 1)):
+        S = E.op_decode_swizzle(which, W)
+        kw = dict(out_dtype=torch.float32) if epi == 6 else {}
+        a = E.op_gemm(epi, A, W, kernel=3, **kw)
+        b = E.op_gemm(epi, A, W, kernel=3, decode_layout=(kind, S), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (which, M)
+        assert float(a.float().abs().max()) > 0
