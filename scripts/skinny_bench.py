@@ -15,7 +15,14 @@ for M in (int(a) for a in (sys.argv[1:] or ['32', '64'])):
         A = (torch.rand(M, K, device='cuda', generator=g) * 2 - 1).bfloat16()
         Ws = [((torch.rand(N, K, device='cuda', generator=g) * 2 - 1) * 0.05).bfloat16() for _ in range(3)]
         res = torch.zeros(M, N, device='cuda', dtype=torch.bfloat16) if epi == 3 else None
-        f = lambda W: E.op_gemm(epi, A, W, res=res)
+        out = E.op_gemm(epi, A, Ws[0], res=res)                    # preallocated: a fresh zero-filled output per call would be timed too
+        which = {'wqkv': 0, 'wo': 1, 'w1w3': 2, 'w2': 3}[name]
+        if os.environ.get('LAYOUT'):                               # the decode-layout copies cr_finalize keeps (wqkv's RoPE tile order needs the K-sliced form)
+            kind = 2 if (which == 0 and epi == 7) else 1
+            SW = {id(W): E.op_decode_swizzle(which if kind == 2 or which else 1, W) for W in Ws}
+            f = lambda W: E.op_gemm(epi, A, W, res=res, out=out, decode_layout=(kind, SW[id(W)]))
+        else:
+            f = lambda W: E.op_gemm(epi, A, W, res=res, out=out)
         for W in Ws: f(W)
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
