@@ -551,6 +551,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             const int brow = n0 + (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + srow;
             qA[h] = (uint32_t)(((int64_t)min(arow, p.M - 1) * p.lda + schunk * 8) * 2);
             qB[h] = (uint32_t)(((int64_t)min(brow, p.N - 1) * p.ldw + schunk * 8) * 2);
+#ifdef CR_KO_WCONTIG      // knock-out (wrong results, cost structure only): the weight panel read as contiguous KiB blocks, what a pre-tiled copy would allow
+            qB[h] = (uint32_t)((int64_t)n0 * p.ldw * 2 + (h * 8 + wave) * 2048 + (lane & 63) * 16);
+#endif
+#ifdef CR_KO_AROWS        // knock-out: an activation instruction reads 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B
+            qA[h] = (uint32_t)(((int64_t)min(arow - srow + (lane >> 3), p.M - 1) * p.lda + (lane & 7) * 8) * 2);
+#endif
         }
     };
     auto dma = [&](const bf16* base, uint32_t o, int kt, int buf, int u) {
@@ -569,6 +575,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
 #endif
         const char* src = (const char*)base + (int64_t)kt * (BK2 * 2);
+#if defined(CR_KO_WCONTIG) || defined(CR_KO_AROWS)
+        {
+            bool alt = false;
+            int64_t second = 0;
+#ifdef CR_KO_WCONTIG
+            if (base == p.W) { alt = true; src = (const char*)base + (int64_t)kt * (256 * BK2 * 2); second = 1024; }
+#endif
+#ifdef CR_KO_AROWS
+            if (base == p.A) { alt = true; second = (int64_t)8 * p.lda * 2; }
+#endif
+            if (alt) {
+                __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(CR_GLB(src + o + second), CR_LDS(dst + 1024), 16, 0, 0);
+                return;
+            }
+        }
+#endif
         __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst), 16, 0, 0);
         // the instruction's immediate offset is added to the global AND to the LDS address: M0 is set 64 short
         __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst + 1024 - 64), 16, 64, 0);
