@@ -286,6 +286,9 @@ def main():
         raise SystemExit('bench.py needs a GPU: there is no CPU fallback for the hot path')
     if backend == 'nccl' and world > n_dev:
         raise SystemExit(f'{world} ranks but {n_dev} visible GPU(s): RCCL needs one GPU per rank (CR_DIST_BACKEND=gloo shares a GPU on a test box)')
+    if world > 2 * n_dev:
+        # plumbing runs with many ranks on one GPU (gloo): every rank would keep the decode-layout copy of the LLM (+15.9 GB each) beside its model
+        os.environ.setdefault('CR_DECODE_LAYOUT', '0')
     local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)

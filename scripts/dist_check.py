@@ -16,6 +16,8 @@ from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 backend = os.environ.get('CR_DIST_BACKEND', 'nccl')
+if int(os.environ.get('WORLD_SIZE', '1')) > 2 * torch.cuda.device_count():
+    os.environ.setdefault('CR_DECODE_LAYOUT', '0')       # many ranks sharing one GPU: no second copy of the LLM per rank
 dev_idx = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
 torch.cuda.set_device(dev_idx)
 dist.init_process_group(backend)
