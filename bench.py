@@ -540,7 +540,9 @@ def main():
                                    f'{S_page}-token prompt, {NEW_TOKENS} greedy tokens, repetition_penalty 1.0); InternVL2-8B shapes '
                                    '(InternViT-300M 24L + mlp1 + PerceiverResampler 4L + 92553-row cosine VQ + InternLM2.5-7B 32L), random-init bf16 weights',
                        'scaling': args.scaling, 'pages_per_step': n_pages, 'pages_per_gpu': P, 'tiles_per_page': PAGE_TILES + CHAR_TILES, 'prompt_tokens': S_page, 'new_tokens': NEW_TOKENS,
-                       'parallelism': f'character tiles sharded over ranks + RCCL all-gather of their pseudo-token embeddings, page tiles and LLM per page owner (round-robin), dp{world}'},
+                       'parallelism': f'character tiles sharded over ranks + RCCL all-gather of their pseudo-token embeddings, page tiles and LLM per page owner (round-robin), dp{world}',
+                       'decode_weight_layout': 'nn.Linear rows (CR_DECODE_LAYOUT=0)' if os.environ.get('CR_DECODE_LAYOUT') == '0' else
+                                               'second, tile-contiguous copy of every LLM linear for the weight-streaming decode kernels (+15.9 GB per GPU, bit-identical results)'},
             'roofline': {'bound': 'mfma', 'kernel': 'tiled bf16 MFMA GEMM (gemm256_kernel, persistent 256x256, slot-staggered wave groups; gemm128_kernel where it schedules better), launches with M >= 1024: ViT, projector, resampler to_kv, VQ, LLM prefill',
                          'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
