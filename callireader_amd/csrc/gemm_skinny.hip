@@ -63,6 +63,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
     const bf16* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) xp[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq;
+#ifdef CR_KO_XFRAG      // knock-out (wrong results, cost structure only): the activations read as if stored in fragment layout, a contiguous KiB per load instruction
+    constexpr int XSTEP = 512;
+#pragma unroll
+    for (int t = 0; t < MT; t++) xp[t] = p.A + (int64_t)min(t * 16, max(p.M - 16, 0)) * p.lda + (kbase / 32) * 512 + lane * 8;
+#else
+    constexpr int XSTEP = 32;
+#endif
 
     constexpr int UR = UNROLL / RT;
     f32x4 acc[RT][MT];
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
 #pragma unroll
         for (int t = 0; t < MT; t++)
 #pragma unroll
-            for (int u = 0; u < UR; u++) x[t][u] = *(const bf16x8*)(xp[t] + (ks + u) * 32);
+            for (int u = 0; u < UR; u++) x[t][u] = *(const bf16x8*)(xp[t] + (ks + u) * XSTEP);
 #pragma unroll
         for (int u = 0; u < UR; u++)
 #pragma unroll
