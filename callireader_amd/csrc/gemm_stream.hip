@@ -1,4 +1,4 @@
-// Weight-streaming GEMM for decode, second form:  C[M,N] = epi(X[M,K] . W[N,K]^T),  16 < M <= 64 rows, N > 8192, K % 2048 == 0, bf16 weights
+// Weight-streaming GEMM for decode, second form:  C[M,N] = epi(X[M,K] . W[N,K]^T),  8 < M <= 64 rows, N > 8192, K % 2048 == 0, bf16 weights
 // (w1|w3 and the LM head when more than 16 pages decode together).
 //
 // gemm_skinny.hip splits K over the waves of a workgroup, so a workgroup's 64 weight rows take the whole X (M x K) through the CU's
@@ -167,6 +167,7 @@ int launch_mt(const GemmParams& p, hipStream_t stream, int splits, int nw) {
 template <int EPI>
 int launch_e(const GemmParams& p, hipStream_t stream, int splits, int nw) {
     switch ((p.M + 15) / 16) {
+        case 1: return launch_mt<EPI, 1>(p, stream, splits, nw);
         case 2: return launch_mt<EPI, 2>(p, stream, splits, nw);
         case 3: return launch_mt<EPI, 3>(p, stream, splits, nw);
         case 4: return launch_mt<EPI, 4>(p, stream, splits, nw);
@@ -197,7 +198,8 @@ int gemm_stream_waves(int N, int splits) {
 
 bool gemm_stream_supported(int epi, const GemmParams& p, int splits) {
     // exactly the launches gemm_skinny.hip would run with FOUR waves over K and whose quarters are whole 256-deep chunks
-    if (p.w8 || p.a8 || p.M <= 16 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
+    // (9..16 rows too since the weights have their decode layout: w1|w3 at 16 rows 48 -> 41 us; up to 8 rows gemm_decode.hip's kernels run)
+    if (p.w8 || p.a8 || p.M <= 8 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
     if ((p.lda & 7) || (!p.wsw && (p.ldw & 7)) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;
