@@ -199,7 +199,8 @@ int gemm_stream_waves(int N, int splits) {
 bool gemm_stream_supported(int epi, const GemmParams& p, int splits) {
     // exactly the launches gemm_skinny.hip would run with FOUR waves over K and whose quarters are whole 256-deep chunks
     // (9..16 rows too since the weights have their decode layout: w1|w3 at 16 rows 48 -> 41 us; up to 8 rows gemm_decode.hip's kernels run)
-    if (p.w8 || p.a8 || p.M <= 8 || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
+    static const int min_rows = [] { const char* e = getenv("CR_STREAM_MIN"); return e ? atoi(e) : 8; }();      // tuning aid
+    if (p.w8 || p.a8 || p.M <= min_rows || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
     if ((p.lda & 7) || (!p.wsw && (p.ldw & 7)) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;
