@@ -86,6 +86,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         const unsigned char* w8p[RT];
 #pragma unroll
         for (int r = 0; r < RT; r++) w8p[r] = (const unsigned char*)p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq16;
+#ifdef CR_KO_W8CONTIG   // knock-out (wrong results, cost structure only): the e4m3 weights read as contiguous KiB blocks, what a decode layout of the fp8 copies would give
+        constexpr int W8STEP = 1024;
+#pragma unroll
+        for (int r = 0; r < RT; r++) w8p[r] = (const unsigned char*)p.W + ((int64_t)min(n0 / 16 + r, (p.N + 15) / 16 - 1) * (p.K / 64) + kbase / 64) * 1024 + lane * 16;
+#else
+        constexpr int W8STEP = 64;
+#endif
         const bf16* x8p[MT];
 #pragma unroll
         for (int t = 0; t < MT; t++) x8p[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq16;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
 #pragma unroll
             for (int r = 0; r < RT; r++)
 #pragma unroll
-                for (int u = 0; u < U8; u++) w[r][u] = __builtin_nontemporal_load((const u32x4_t*)(w8p[r] + (s8 + u) * 64));
+                for (int u = 0; u < U8; u++) w[r][u] = __builtin_nontemporal_load((const u32x4_t*)(w8p[r] + (s8 + u) * W8STEP));
 #pragma unroll
             for (int t = 0; t < MT; t++)
 #pragma unroll
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         for (; s8 < steps; s8++) {
 #pragma unroll
             for (int r = 0; r < RT; r++) {
-                const u32x4_t w = __builtin_nontemporal_load((const u32x4_t*)(w8p[r] + s8 * 64));
+                const u32x4_t w = __builtin_nontemporal_load((const u32x4_t*)(w8p[r] + s8 * W8STEP));
                 const bf16x8 w0 = fp8x8_to_bf16(w[0], w[1]), w1 = fp8x8_to_bf16(w[2], w[3]);
 #pragma unroll
                 for (int t = 0; t < MT; t++) {

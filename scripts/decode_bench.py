@@ -23,6 +23,7 @@ for i0 in range(0, P, 16):
     idx = list(range(i0, min(P, i0 + 16)))
     eng.prefill_batch(kv, idx, [embeds[i] for i in idx], penalty=1.0)
 live = list(range(P))
+if os.environ.get('FP8'): eng.enable_fp8_decode(True)      # e4m3 copies of the LLM's linears for the decode GEMMs (an option)
 for _ in range(4):
     eng.decode(kv, live, penalty=1.0)
 torch.cuda.synchronize()
