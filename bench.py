@@ -83,6 +83,18 @@ def plan_workload(scaling, pages, total_pages, world, rank):
     return {'scaling': scaling, 'n_pages': n_pages, 'mine': mine, 'ct_lo': ct_lo, 'ct_hi': ct_hi, 'pages_per_gpu': len(mine)}
 
 
+def plan_strong_share(total_pages, share_world):
+    """The workload `strong_share` runs on ONE GPU: as much as rank 0 of plan_workload('strong', total_pages over share_world ranks) has -- the same
+    number of owned pages and of character tiles -- but laid on pages 0 .. n-1 of the one-GPU step and their own character tiles (a rank of the real
+    run owns pages r, r + world, ... and an arbitrary eighth of the character tiles: the same work), so that the ids can be compared with the
+    full step's.  Needs an even split (total_pages % share_world == 0)."""
+    sw = plan_workload('strong', total_pages, total_pages, share_world, 0)
+    n_own, n_ct = sw['pages_per_gpu'], sw['ct_hi'] - sw['ct_lo']
+    if n_ct != n_own * CHAR_TILES:
+        raise ValueError(f'{total_pages} pages over {share_world} ranks: uneven split')
+    return {'scaling': 'strong', 'n_pages': n_own, 'mine': list(range(n_own)), 'ct_lo': 0, 'ct_hi': n_ct, 'pages_per_gpu': n_own}
+
+
 # the one whole-page CPU measurement on record (profiles/round3/01_bench_N1_default_full_cpu_baseline.json, AMD EPYC 9575F, 64 threads): the
 # sampled extrapolation of the same run said 165 s per page, the oracle measured stage by stage took 231 s
 CPU_FULL_PAGE_MEASURED_S, CPU_FULL_PAGE_SAMPLED_S = 231.0, 165.0
@@ -269,6 +281,9 @@ def main():
     ap.add_argument('--no-strong-block', action='store_true',
                     help='N > 1 with weak scaling: do not append the strong-scaling block (BASELINE config 4 as written: --total-pages per step over all ranks) to the line')
     ap.add_argument('--strong-steps', type=int, default=2, help='timed steps of that block')
+    ap.add_argument('--no-strong-share', action='store_true', help='N = 1: do not time one rank\'s share of the strong-scaling step (strong_share)')
+    ap.add_argument('--share-world', type=int, default=8, help='the world size whose rank-0 share strong_share runs on this one GPU')
+    ap.add_argument('--share-steps', type=int, default=2, help='timed steps of strong_share')
     ap.add_argument('--fp8-extras', action='store_true', help='also time the batched decode on e4m3 weight copies (fp8_decode; 1.03-1.09x at 64 rows, so not in the default line)')
     ap.add_argument('--no-pipeline', action='store_true', help='one batch at a time (the decode of a batch does not run beside the visual stage of the next)')
     args = ap.parse_args()
@@ -447,7 +462,7 @@ def main():
     gather = gather_standalone(wl) if world > 1 else None
 
     # one un-pipelined step for comparison (untimed extra) and a self-check: the pipelined run's ids are the sequential step's
-    seq_ms, same_ids, seq_frac, seq_dec = None, None, None, None
+    seq_ms, same_ids, seq_frac, seq_dec, seq_out = None, None, None, None, None
     if pipe is not None:
         last_pipe = run_steps(1)[-1]
         if os.environ.get('CR_PIPE_MARKS') and pipe.host_steps:
@@ -479,6 +494,54 @@ def main():
                    'visual_ms': round((st[1] - st[0]) * 1e3, 1), 'prefill_ms': round((st[2] - st[1]) * 1e3, 1),
                    'tflops': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12, 1),
                    'mfma_frac': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    # ---- N = 1: one rank's SHARE of BASELINE config 4 as written (64 pages over 8 GPUs), timed on the one GPU there is ----
+    # The only evidence for north_star's ">= 6x at 8 GPUs" that can exist without a node: plan ('strong', 64 pages, world 8, rank 0) = 8 pages to own
+    # (88 page tiles, 8 prompts, NEW_TOKENS - 1 eight-row decode steps) + an eighth of the character tiles (768), run alone on this GPU, one batch at
+    # a time, next to the 64-page step of the same run.  The share's pages are pages 0..7 of the 64-page step (a rank of the real run owns pages
+    # r, r + 8, ...: the same amount of work), so that the ids can be compared: a page's result does not depend on its batch.
+    strong_share = None
+    if world == 1 and rank == 0 and args.scaling == 'weak' and not args.no_strong_share and args.pages >= args.share_world and args.pages % args.share_world == 0:
+        w_share = plan_strong_share(args.pages, args.share_world)
+        n_own, n_ct = w_share['pages_per_gpu'], w_share['ct_hi']
+        ins = (page_px[:n_own * PAGE_TILES], char_px[:n_ct], ids[:n_own])
+        step(w=w_share, inputs=ins)                                # untimed warm-up (workspace sizes, kernel attributes of the 8-row forms)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        share_out = None
+        for _ in range(args.share_steps):
+            share_out = step(w=w_share, inputs=ins)
+        torch.cuda.synchronize()
+        t_share = (time.perf_counter() - t0) / args.share_steps
+        st3 = [0.0]
+        torch.cuda.synchronize(); st3[0] = time.perf_counter()
+        step(new_tokens=1, stamps=st3, w=w_share, inputs=ins)
+        full_ms = seq_ms
+        full_out = seq_out
+        if full_ms is None:                                        # --no-pipeline: the timed steps were one batch at a time already
+            full_ms = elapsed / args.steps * 1e3
+            full_out = step()
+            torch.cuda.synchronize()
+        same_share = bool(share_out == full_out[:n_own])
+        vis_ms, pre_ms = (st3[1] - st3[0]) * 1e3, (st3[2] - st3[1]) * 1e3
+        strong_share = {
+            'what': f'one rank\'s share of BASELINE config 4 as written ({args.pages} pages per step over {args.share_world} GPUs, plan_workload(strong, rank 0)) run ALONE on this one GPU, '
+                    f'one batch at a time: {n_own} pages owned ({n_own * PAGE_TILES} page tiles, {n_own} prompts of {S_page} tokens, {NEW_TOKENS - 1} decode steps of {n_own} rows) '
+                    f'+ {n_ct} of the {args.pages * CHAR_TILES} character tiles',
+            'world_projected': args.share_world, 'pages_owned': n_own, 'char_tiles': n_ct, 'steps': args.share_steps,
+            't_share_ms': round(t_share * 1e3, 2),
+            'phases_ms': {'visual': round(vis_ms, 1), 'splice_prefill_first_token': round(pre_ms, 1),
+                          'decode_remaining_tokens': round(max(t_share * 1e3 - vis_ms - pre_ms, 0.0), 1),
+                          'decode_ms_per_step': round(max(t_share * 1e3 - vis_ms - pre_ms, 0.0) / max(NEW_TOKENS - 1, 1), 4),
+                          'how': 'one extra stamped pass that stops after the first token; decode = timed share - those two'},
+            'full_step_one_batch_at_a_time_ms': round(full_ms, 1),
+            f'projected_speedup_{args.share_world}': round(full_ms / (t_share * 1e3), 3),
+            f'projected_speedup_{args.share_world}_vs_pipelined_n1': round((elapsed / args.steps * 1e3) / (t_share * 1e3), 3),
+            'projection_note': f'upper bound: ms of the {args.pages}-page step on one GPU / ms of one rank\'s share; excludes the all-gather (24.5 KB per character tile, '
+                               'started under the page tiles\' ViT) and rank skew (every rank has the same tile and page counts at 64 pages over 8); '
+                               'the second ratio is against the headline N = 1 step (two batches in flight)',
+            'ids_equal_the_same_pages_of_the_full_step': same_share}
+        del ins
 
     # ---- N > 1, weak scaling (what the driver's one command runs): BASELINE config 4 AS WRITTEN in the same process group ----
     # `--total-pages` per step over ALL ranks (64 pages over 8 GPUs = 8 per GPU): the number north_star's ">= 6x at 8 GPUs" is about.  Weak scaling
@@ -568,6 +631,7 @@ def main():
             'prof': {'launches_bracketed': int(pstat[0]), 'accounted': int(pstat[1]), 'lost': int(pstat[2]), 'peak_pending': int(pstat[3])},
             'all_gather': gather,
             'strong_scaling': strong,
+            'strong_share': strong_share,
             'pipeline': None if pipe is None else {
                 'what': 'two batches in flight (PagePipeline): a worker thread runs the HBM-bound batched decode of batch i-1 on a second HIP stream '
                         '(second context sharing the weights) beside the matrix-bound visual stage and prefill of batch i; a run of K steps ends '

@@ -139,6 +139,7 @@ int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     { const char* e = getenv("CR_NO_SLICED_DECODE"); c->no_sliced_decode = e && atoi(e) != 0; }
     { const char* e = getenv("CR_DECODE_GRAPH"); if (e) c->decode_graph = atoi(e) != 0; }
     { const char* e = getenv("CR_DECODE_FUSED"); if (e) c->fused_decode = atoi(e) != 0; }
+    { const char* e = getenv("CR_PREFILL_LAST_ROWS"); if (e) c->prefill_last_rows = atoi(e) != 0; }
     c->scratch_bytes = 1 << 20;
     if (hipMalloc((void**)&c->scratch, c->scratch_bytes) != hipSuccess) { delete c; return cr_fail(CR_ERR_NOMEM, "scratch"); }
     hipMemset(c->scratch, 0, c->scratch_bytes);
@@ -200,6 +201,26 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
     CR_HIP(hipMemcpyAsync(t.ptr, src, t.bytes, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (src_is_host) CR_HIP(hipStreamSynchronize((hipStream_t)stream));   // caller may free host memory right away
     c->w[name] = t;
+    // copies cr_finalize / cr_enable_fp8_* derived from the tensor this one replaces (decode layout, e4m3 bytes + scales, fc1's bound) would go on
+    // serving the OLD values to the kernels that read them (round-4 advice): they go now, cr_finalize rebuilds the decode layout, and the fp8
+    // options switch off until cr_enable_fp8_* is called again (it rebuilds what is missing)
+    bool had_fp8 = false;
+    for (const char* pre : {"declayout.", "fp8.", "fp8s.", "fp8b."}) {
+        auto d = c->w.find(std::string(pre) + name);
+        if (d == c->w.end()) continue;
+        if (pre[0] == 'f') had_fp8 = true;
+        hipFree(d->second.ptr);
+        c->w.erase(d);
+    }
+    {   // fc1's bound {max row norm of W1, max |b1|} also depends on the bias
+        const std::string nm(name);
+        const size_t at = nm.rfind("mlp.fc1.bias");
+        if (at != std::string::npos && at + 12 == nm.size()) {
+            auto d = c->w.find("fp8b." + nm.substr(0, at) + "mlp.fc1.weight");
+            if (d != c->w.end()) { hipFree(d->second.ptr); c->w.erase(d); had_fp8 = true; }
+        }
+    }
+    if (had_fp8) { c->fp8_decode = false; c->fp8_mfma = 0; }
     cr_bump_gen(c);
     if (strncmp(name, "orderformer.", 12) != 0) c->finalized = false;      // the sorter (f4) has no derived tensors to refresh
     return CR_OK;

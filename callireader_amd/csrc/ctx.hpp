@@ -33,7 +33,8 @@ struct cr_ctx {
                                         // matrix cores; 2 = also the linears whose input no norm produces (ViT fc2 via fc1's e4m3 epilogue, LLM wo / w2 via a quantiser pass)
     bf16* probe_dst = nullptr;          // cr_llm_hidden_probe: [layers + 1][probe_rows][4096] rows of the residual stream of the next prefills
     int probe_row0 = 0, probe_rows = 0;
-    bool fused_decode = true;           // decode batches of <= 16 rows take gemm_decode.hip (six launches per layer, the same bits); CR_DECODE_FUSED=0: the separate kernels
+    bool fused_decode = true;           // decode batches of <= DECODE_FUSED_MAX_ROWS (8) rows take gemm_decode.hip (six launches per layer, the same bits); CR_DECODE_FUSED=0: the separate kernels
+    bool prefill_last_rows = true;      // prefill: the final decoder layer's attention / wo / w1|w3 / w2 on each page's last row only (bit-identical; CR_PREFILL_LAST_ROWS=0: all rows)
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
     std::unordered_map<std::string, DevTensor> w;
     // workspace

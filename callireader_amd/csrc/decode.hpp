@@ -4,6 +4,10 @@
 
 constexpr int DECODE_FUSED_MAX_ROWS = 8;     // beyond this the separate kernels are faster (gemm_decode.hip's header, profiles/round4/)
 
+// K-slice counts the fused kernels reproduce as "virtual slices": they must be gemm_skinny.hip's partial_geom() picks for the same shapes, or a row's bits
+// would differ between a <= 8-row batch (fused) and a larger one (K-sliced partials summed by the consumer); run_layers checks it before taking the fused path
+constexpr int DEC_SLICES_WQKV = 2, DEC_SLICES_WO = 4, DEC_SLICES_W2 = 4;
+
 enum DecodeGemm { DEC_WQKV = 0, DEC_WO = 1, DEC_W13 = 2, DEC_W2 = 3, DEC_HEAD = 4 };
 
 struct DecodeGemmParams {

@@ -12,7 +12,9 @@ extern "C" int cr_finalize(cr_ctx* c, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (c->w.count("vision_model.embeddings.patch_embedding.weight")) CR_TRY(vit_finalize(c, st));
     if (c->w.count("normed_emb.weight")) CR_TRY(calli_finalize(c, st));
-    if (c->w.count("language_model.model.layers.0.feed_forward.w1.weight")) CR_TRY(llm_finalize(c, st));
+    // (w1 / w3 are released once interleaved: a context finalized before still has its language model -- a reloaded wqkv / wo / w2 / LM head
+    //  needs its decode-layout copy rebuilt just the same)
+    if (c->w.count("language_model.model.layers.0.feed_forward.w1.weight") || c->w.count("derived.w13.0")) CR_TRY(llm_finalize(c, st));
     CR_HIP(hipStreamSynchronize(st));
     c->finalized = true;
     cr_bump_gen(c);

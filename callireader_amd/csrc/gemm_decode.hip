@@ -241,6 +241,9 @@ int launch_one(const DecodeGemmParams& p, int grid_cap, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};
     if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW>, 160 * 1024)) return CR_ERR_HIP;
     const int grid = grid_cap > 0 && grid_cap < sets ? grid_cap : sets;
+    // the look-ahead across a tile boundary leaves the next tile's batches 0 / 1 in wr[(NB - 2) & 1] / wr[(NB - 1) & 1]: right for an even number of batches only,
+    // so an odd one (w2: 7) must never walk a second tile
+    if ((VS * KPR / 8) % 2 != 0 && grid < sets) return CR_ERR_ARG;
     hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW>), dim3(grid), dim3(TG * KW * 64), lds, st, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
@@ -303,17 +306,17 @@ static int launch_decode_gemm_(int which, const DecodeGemmParams& p, hipStream_t
     switch (which) {
         case DEC_WQKV:
             if (p.N != 6144 || p.K != 4096 || !p.xres || !p.gamma || !p.cosT || !p.sinT || !p.q_out || !p.kc || !p.vc || !p.seqs || !p.lens) return CR_ERR_ARG;
-            return launch_one<DEPI_ROPE, 8, 2, 8, true, 1, true>(p, 0, st);              // one tile per workgroup: sums alias the normalised rows
+            return launch_one<DEPI_ROPE, 8, DEC_SLICES_WQKV, 8, true, 1, true>(p, 0, st);              // one tile per workgroup: sums alias the normalised rows
         case DEC_WO:
             if (p.N != 4096 || p.K != 4096 || !p.X || !p.xio) return CR_ERR_ARG;
-            return launch_one<EPI_RES, 8, 4, 4, false>(p, 0, st);
+            return launch_one<EPI_RES, 8, DEC_SLICES_WO, 4, false>(p, 0, st);
         case DEC_W13:
             if (p.N != 2 * 14336 || p.K != 4096 || !p.xres || !p.gamma || !p.C) return CR_ERR_ARG;
             if (p.M > 4) return launch_one<EPI_SWIGLU, 4, 1, 32, true, 2>(p, g13 / 2, st);      // two tiles at a time on shared rows: 16 waves per CU at 5..8 rows
             return launch_one<EPI_SWIGLU, 4, 1, 32, true>(p, g13, st);
         case DEC_W2:
             if (p.N != 4096 || p.K != 14336 || !p.X || !p.xio) return CR_ERR_ARG;
-            return launch_one<EPI_RES, 8, 4, 14, false>(p, 0, st);
+            return launch_one<EPI_RES, 8, DEC_SLICES_W2, 14, false>(p, 0, st);
         case DEC_HEAD:
             if (p.K != 4096 || !p.xres || !p.gamma || !p.C) return CR_ERR_ARG;
             if (p.M > 4) return launch_one<EPI_F32, 4, 1, 32, true, 2>(p, ghead / 2, st);

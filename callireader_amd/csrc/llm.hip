@@ -110,6 +110,17 @@ __global__ __launch_bounds__(256) void splice_rows_kernel(const bf16* __restrict
     dp[threadIdx.x + 256] = sp[threadIdx.x + 256];
 }
 
+// dst[i] = src[idx[i]] (GATHER) or dst[idx[i]] = src[i]: rows of 4096 bf16 (the last prompt row of every page around the final layer's row-wise tail)
+template <bool GATHER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const bf16* __restrict__ src, const int32_t* __restrict__ idx, bf16* __restrict__ dst) {
+    const int i = blockIdx.x;
+    const int64_t r = idx[i];
+    const bf16x8* sp = (const bf16x8*)(src + (GATHER ? r : (int64_t)i) * D);
+    bf16x8* dp = (bf16x8*)(dst + (GATHER ? (int64_t)i : r) * D);
+    dp[threadIdx.x] = sp[threadIdx.x];
+    dp[threadIdx.x + 256] = sp[threadIdx.x + 256];
+}
+
 // RoPE + split of the fused wqkv output (modeling_internlm2.py:359-388, 233-247).
 // qkv row = [8 groups][4 q | k | v][128].  q_embed = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), same for k.
 // grid (rows, 8 groups), 128 threads: thread = (slot 0..7 [6 used], 16-B chunk 0..15).
@@ -323,8 +334,10 @@ int layer_weights(cr_ctx* c, int l, LayerW& w) {
 struct Segment { int seq, row0, S, pos0; };     // a page's rows inside a batched prefill
 
 // The decoder stack over M rows (prefill: M = all prompt rows of the pages in `segs`; decode: M = n sequences, one row each).
+// d_last / d_seg_last (prefill): the pages' last rows and, as attention segments, the rows that share a wave with them -- see the final layer below.
 int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vector<Segment>& segs, const int32_t* d_row_seq,
-               const int32_t* d_row_pos, const int32_t* d_seqs, int nsplit, hipStream_t st, const int32_t* d_seg = nullptr) {
+               const int32_t* d_row_pos, const int32_t* d_seqs, int nsplit, hipStream_t st, const int32_t* d_seg = nullptr,
+               const int32_t* d_last = nullptr, const int32_t* d_seg_last = nullptr) {
     const int ff = (int)WT(c, "derived.w13.0")->shape[0] / 2;
     Arena ar(c->ws);
     float* part = decode ? ar.take<float>(attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD)) : nullptr;
@@ -336,6 +349,18 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
     float* hs = ar.take<float>((size_t)M);          // fp8 matrix-core path: one scale per normalised row
     const bool any8 = !decode && c->fp8_mfma && M >= 256;
     unsigned char* a8 = any8 ? ar.take<unsigned char>((size_t)M * ff) : nullptr;     // e4m3 rows of the attention output / the SwiGLU output
+    // Prefill, FINAL layer: only each page's last row is ever read again (the LM head, :1081-1082 + _sample; the reference computes every row).  K / V of
+    // every row still go to the cache, so the norm, wqkv and RoPE + split run on all rows; attention, wo, the second norm, w1|w3 and w2 run on the n last rows
+    // only -- 88 % of that layer's linear work.  Bit-exact: the tiled kernels give a row the same sum whatever it is batched with (pinned, as for short
+    // prompts), and the attention launch keeps a last row in the company of the rows that share its WAVE in the full launch (the kernel's deferred-rescale vote
+    // is wave-wide): segment = {first row of that 32-row group, rows up to the last, their first position}.  CR_PREFILL_LAST_ROWS=0: every row (A/B aid).
+    const int n_pages = (int)segs.size();
+    const bool last_rows_only = !decode && c->prefill_last_rows && d_last && d_seg_last && !any8 && !c->probe_dst && n_pages > 0;
+    bf16 *xl = nullptr, *aol = nullptr, *hl2 = nullptr, *actl = nullptr;
+    if (last_rows_only) {
+        xl = ar.take<bf16>((size_t)n_pages * D); aol = ar.take<bf16>((size_t)n_pages * D); hl2 = ar.take<bf16>((size_t)n_pages * D);
+        actl = ar.take<bf16>((size_t)n_pages * ff);
+    }
     const bf16 *cosT = W(c, "rope.cos"), *sinT = W(c, "rope.sin");
     if (!cosT || !sinT) return CR_ERR_STATE;
     const int64_t per_layer = (int64_t)kv->n_seqs * NKV * kv->max_tokens * HD;
@@ -347,9 +372,11 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
               s_2 = decode ? gemm_partial_splits(D, ff) : 0;
     const bool sliced = decode && M <= 64 && s_qkv > 0 && s_o > 0 && s_2 > 0 && !c->no_sliced_decode;
     float* pbuf = sliced ? ar.take<float>((size_t)std::max(s_qkv * QKV, std::max(s_o, s_2) * D) * M) : nullptr;
-    // small batches (<= 16 rows): gemm_decode.hip folds the norms, RoPE + split and the residual adds into the five GEMMs -- six launches
-    // per layer instead of nine, every sum in the order of the kernels below (a row's bits do not depend on its batch)
-    const bool fused = sliced && c->fused_decode && !c->fp8_decode && decode_fused_supported(M, ff);
+    // small batches (<= DECODE_FUSED_MAX_ROWS = 8 rows): gemm_decode.hip folds the norms, RoPE + split and the residual adds into the five GEMMs -- six launches
+    // per layer instead of nine, every sum in the order of the kernels below (a row's bits do not depend on its batch): its virtual slices are
+    // compiled in, so the path is only taken while the K-sliced kernels' geometry (cost model or CR_PARTIAL_GEOM) is the one they reproduce
+    const bool fused = sliced && c->fused_decode && !c->fp8_decode && decode_fused_supported(M, ff) &&
+                       s_qkv == DEC_SLICES_WQKV && s_o == DEC_SLICES_WO && s_2 == DEC_SLICES_W2;
     // cr_llm_hidden_probe (parity tooling): rows [row0, row0 + rows) of the residual stream before layer 0 and after every layer
     auto probe = [&](int slot) -> int {
         if (!c->probe_dst || decode || c->probe_row0 + c->probe_rows > M) return CR_OK;
@@ -413,6 +440,20 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         ap.K = kc; ap.V = vc; ap.Q = q; ap.O = ao;
         ap.k_bs = ap.v_bs = (int64_t)NKV * kv->max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)kv->max_tokens * HD;
         ap.q_prescale = 1.0f; ap.s_div = 11.313708498984761f;      // math.sqrt(128)
+        if (last_rows_only && l + 1 == c->d.llm_layers) {
+            ap.q_bs = 0; ap.q_rs = D; ap.q_hs = HD; ap.o_bs = 0; ap.o_rs = D; ap.o_hs = HD;
+            ap.H = NH; ap.kv_group = NH / NKV; ap.B = n_pages; ap.seg = d_seg_last; ap.Sq = 32;
+            if (launch_flash_attn(ap, HD, true, st) != CR_OK) return cr_fail(CR_ERR_HIP, "prefill attention launch failed");
+            hipLaunchKernelGGL(move_rows_kernel<true>, dim3(n_pages), dim3(256), 0, st, ao, d_last, aol);
+            hipLaunchKernelGGL(move_rows_kernel<true>, dim3(n_pages), dim3(256), 0, st, x, d_last, xl);
+            // (rows <= 64 are pinned to the tiled kernel by `prefill_rows`; more pages than that take it by the dispatcher's own rule)
+            CR_TRY(gemm(c, EPI_RES, aol, D, w.wo, D, xl, D, xl, D, n_pages, D, D, st, true));
+            CR_TRY(rms(xl, D, hl2, w.fn, n_pages, c->d.rms_eps, st));
+            CR_TRY(gemm(c, EPI_SWIGLU, hl2, D, w.w13, D, actl, ff, nullptr, 0, n_pages, 2 * ff, D, st, true));
+            CR_TRY(gemm(c, EPI_RES, actl, ff, w.w2, ff, xl, D, xl, D, n_pages, D, ff, st, true));
+            hipLaunchKernelGGL(move_rows_kernel<false>, dim3(n_pages), dim3(256), 0, st, xl, d_last, x);
+            continue;
+        }
         if (!decode) {
             ap.q_bs = 0; ap.q_rs = D; ap.q_hs = HD; ap.o_bs = 0; ap.o_rs = D; ap.o_hs = HD;
             ap.B = 1; ap.H = NH; ap.kv_group = NH / NKV;
@@ -470,10 +511,11 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
     return CR_OK;
 }
 
-size_t layers_ws(cr_ctx* c, int M, int nsplit = 0) {
+size_t layers_ws(cr_ctx* c, int M, int nsplit = 0, int n_pages = 0) {
     const size_t ff = (size_t)WT(c, "derived.w13.0")->shape[0] / 2;
+    const size_t last_rows = (size_t)n_pages * (3 * D + ff) * 2 + 4 * 256;      // the final layer's compact rows (prefill)
     const size_t sliced = nsplit > 0 && M <= 64 ? (size_t)8 * QKV * M * 4 : 0;       // K-slice partial sums of the decode GEMMs
-    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + (size_t)M * 4 + (size_t)M * ff + 8192;
+    return ((size_t)M * D * 4 + (size_t)M * QKV + (size_t)M * ff) * 2 + attn_split_ws_floats(M, NKV, NH / NKV, nsplit, HD) * 4 + sliced + (size_t)M * 4 + (size_t)M * ff + last_rows + 8192;
 }
 
 }  // namespace
@@ -515,6 +557,8 @@ int llm_finalize(cr_ctx* c, hipStream_t st) {
         auto i1 = c->w.find(p + "w1.weight"), i3 = c->w.find(p + "w3.weight");
         const std::string dn = "derived.w13." + std::to_string(l);
         if (i1 == c->w.end() || i3 == c->w.end()) {
+            // one of the pair reloaded without the other: the interleaved tensor cannot be rebuilt (the other original was released)
+            if (i1 != c->w.end() || i3 != c->w.end()) return cr_fail(CR_ERR_STATE, "layer %d: reload feed_forward.w1 and w3 together", l);
             if (c->w.count(dn)) continue;          // already derived, originals released
             return cr_fail(CR_ERR_STATE, "layer %d: w1/w3 missing", l);
         }
@@ -563,9 +607,18 @@ int llm_finalize(cr_ctx* c, hipStream_t st) {
         }
         if (ok) {
             const DevTensor* ow = WT(c, "language_model.output.weight");
-            if (ow && ow->shape.size() == 2 && ow->shape[1] == D) derive(DEC_HEAD, "language_model.output.weight", ow->shape[0], D);
+            if (ow && ow->shape.size() == 2 && ow->shape[1] == D) ok = derive(DEC_HEAD, "language_model.output.weight", ow->shape[0], D);
         }
         CR_HIP(hipStreamSynchronize(st));
+        if (want && !ok) {
+            // all or nothing (round-4 advice): a partial set would leave the device nearly full and the decode path on two layouts
+            size_t freed = 0;
+            for (auto it = c->w.begin(); it != c->w.end();) {
+                if (it->first.rfind("declayout.", 0) == 0) { freed += it->second.bytes; hipFree(it->second.ptr); it = c->w.erase(it); } else ++it;
+            }
+            fprintf(stderr, "[callireader_hip] no room (or not the shapes) for the decode-layout copies of the LLM weights: %zu MB released, decode streams the nn.Linear layout\n",
+                    freed >> 20);
+        }
     }
     return CR_OK;
 }
@@ -751,28 +804,35 @@ int cr_llm_prefill_batch(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const
     CR_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = c->d.vocab;
-    const size_t lw = layers_ws(c, M);
-    CR_TRY(ws_ensure(c, lw + (size_t)M * D * 2 + (size_t)n * D * 2 + (size_t)n * V * 4 + (size_t)M * 8 + (size_t)n * 16 + 8192));
+    const size_t lw = layers_ws(c, M, 0, n);
+    CR_TRY(ws_ensure(c, lw + (size_t)M * D * 2 + (size_t)n * D * 2 + (size_t)n * V * 4 + (size_t)M * 8 + (size_t)n * 36 + 8192));
     bf16* x = (bf16*)(c->ws + ((lw + 255) & ~(size_t)255));
     bf16* hl = x + (size_t)M * D;
     float* lg = (float*)(((uintptr_t)(hl + (size_t)n * D) + 255) & ~(uintptr_t)255);
     int32_t* d_row_seq = (int32_t*)(((uintptr_t)(lg + (size_t)n * V) + 255) & ~(uintptr_t)255);
     int32_t* d_row_pos = d_row_seq + M;
     int32_t* d_seg = d_row_pos + M;                 // 4 per page: first row, rows, first position, cache slot (the attention launch's segments)
+    int32_t* d_seg_last = d_seg + 4 * n;            // the final layer's segments: the rows that share a 32-row wave with the page's last row
+    int32_t* d_last = d_seg_last + 4 * n;           // and that last row
     {
-        std::vector<int32_t> h(2 * (size_t)M + 4 * segs.size());
+        std::vector<int32_t> h(2 * (size_t)M + 9 * segs.size());
         for (const Segment& sg : segs)
             for (int r = 0; r < sg.S; r++) { h[sg.row0 + r] = sg.seq; h[(size_t)M + sg.row0 + r] = sg.pos0 + r; }
         for (size_t i = 0; i < segs.size(); i++) {
             int32_t* e = h.data() + 2 * (size_t)M + 4 * i;
             e[0] = segs[i].row0; e[1] = segs[i].S; e[2] = segs[i].pos0; e[3] = segs[i].seq;
+            // the attention kernel's query blocks are 128 rows of a segment, its waves 32: rows [32 k, 32 k + 32) of a page meet in one wave
+            const int w0 = (segs[i].S - 1) / 32 * 32;
+            int32_t* f = h.data() + 2 * (size_t)M + 4 * segs.size() + 4 * i;
+            f[0] = segs[i].row0 + w0; f[1] = segs[i].S - w0; f[2] = segs[i].pos0 + w0; f[3] = segs[i].seq;
+            h[2 * (size_t)M + 8 * segs.size() + i] = segs[i].row0 + segs[i].S - 1;
         }
         CR_HIP(hipMemcpyAsync(d_row_seq, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: staged before return
     }
     CR_HIP(hipMemcpyAsync(kv->d_seqs, seqs, (size_t)n * 4, hipMemcpyHostToDevice, st));
     kv->seqs_on_device.assign(seqs, seqs + n);
     CR_HIP(hipMemcpyAsync(x, embeds, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));
-    CR_TRY(run_layers(c, kv, x, M, false, segs, d_row_seq, d_row_pos, nullptr, 0, st, d_seg));
+    CR_TRY(run_layers(c, kv, x, M, false, segs, d_row_seq, d_row_pos, nullptr, 0, st, d_seg, d_last, d_seg_last));
     const bf16 *nw = W(c, "language_model.model.norm.weight"), *ow = W(c, "language_model.output.weight");
     if (!nw || !ow) return CR_ERR_STATE;
     // only each page's last row feeds the LM head (the reference computes all S rows and reads the last, :1081 + _sample)

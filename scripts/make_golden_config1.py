@@ -88,7 +88,10 @@ def main():
         # second-best cosine per query: how close the reference's own arg-max is to a tie
         xn = torch.nn.functional.normalize(out, p=2, dim=2)
         en = torch.nn.functional.normalize(table.weight, p=2, dim=1)
-        top2 = torch.topk(torch.matmul(xn, en.t()).float(), 2, dim=2).values
+        sim = torch.matmul(xn, en.t()).float()
+        top2 = torch.topk(sim, 2, dim=2).values
+        top8 = torch.topk(sim, 8, dim=2)                 # the reference's own candidates: what the VQ tie rule (oracle/calli_align.py: vq_tie_rule) looks a differing index up in
+        del sim
     tail, _ = reference_tail()
     self_ns = types.SimpleNamespace(normed_emb=types.SimpleNamespace(weight=table.weight.data), mu=vsd['calli.mu'], sigma=vsd['calli.sigma'])
     back, indices2 = tail(self_ns, indices, out.clone(), False, False, False)
@@ -96,6 +99,8 @@ def main():
     gold.update(flat('resampler', sample(out, 8192)))
     gold['vq.indices'] = indices.numpy().astype(np.int64)
     gold['vq.top2_cos'] = top2.numpy()
+    gold['vq.top8_ids'] = top8.indices.numpy().astype(np.int64)
+    gold['vq.top8_cos'] = top8.values.numpy()
     gold.update(flat('pseudo', sample(back, 8192)))
     del rs, rsd, table, xn, en
 

@@ -150,6 +150,75 @@ def test_batched_decode_equals_single(setup):
     kv.free()
 
 
+def test_a_rows_bits_do_not_depend_on_which_kernels_its_batch_takes(setup):
+    """One page decoded alone (gemm_decode.hip's fused kernels), inside a 9-row and inside a 16-row batch (gemm_skinny.hip's K-sliced partials
+    for wqkv / wo / w2, gemm_stream.hip for w1|w3 and the LM head): the logits of every step and the ids must be the same bits (round-4 advice:
+    the 3-row batches of test_batched_decode_equals_single never leave the fused kernels)."""
+    eng = setup['eng']
+    lens = [300, 77, 130, 17, 64, 255, 256, 31, 129, 40, 200, 90, 5, 150, 33, 61]
+    embs = [prompt(S, 700 + i) for i, S in enumerate(lens)]
+    kv1 = eng.kv_alloc(1, 512)
+    eng.prefill(kv1, 0, embs[0].cuda())
+    alone = [eng.decode(kv1, [0], penalty=1.2, want_logits=True).clone() for _ in range(5)]
+    ids_alone = kv1.generated(0)
+    kv1.free()
+    for rows in (9, 16):
+        kv = eng.kv_alloc(rows, 512)
+        for i in range(rows):
+            eng.prefill(kv, i, embs[i].cuda())
+        order = list(range(rows - 1, -1, -1))                         # the page is the LAST row of the batch
+        for step in range(5):
+            lg = eng.decode(kv, order, penalty=1.2, want_logits=True)
+            torch.cuda.synchronize()
+            assert torch.equal(lg[rows - 1], alone[step][0]), (rows, step, float((lg[rows - 1] - alone[step][0]).abs().max()))
+        assert kv.generated(0) == ids_alone
+        kv.free()
+
+
+def test_reloading_a_weight_rebuilds_its_decode_layout(setup):
+    """Round-4 advice (medium): the decode-layout copies cr_finalize keeps of every LLM linear must follow a reload.  A finalized context reloads
+    ONE wqkv, ONE w2 and the LM head (w1 / w3 are long released, so nothing else says "language model" to cr_finalize), finalizes again, and must
+    decode exactly like a fresh context built from the changed state dict -- prefill (nn.Linear layout) and decode (decode layout) alike."""
+    from callireader_amd.engine import Engine
+    from callireader_amd._binding import CalliReaderError
+    dims, sd = setup['dims'], dict(setup['sd'])
+    a = Engine(dims, max_pos=2048)
+    a.load_state_dict(sd); a.load_rope(); a.finalize()
+    emb = prompt(90, 77).cuda()
+    kv = a.kv_alloc(1, 256)
+    a.prefill(kv, 0, emb)
+    before = a.decode(kv, [0], want_logits=True).clone()
+    kv.free()
+    g = torch.Generator().manual_seed(9)
+    changed = {}
+    for k in ('language_model.model.layers.0.attention.wqkv.weight', 'language_model.model.layers.1.feed_forward.w2.weight', 'language_model.output.weight'):
+        changed[k] = (sd[k].float() + 0.01 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
+    for k, v in changed.items():
+        a.load_weight(k, v)
+    a.finalize()
+    sd.update(changed)
+    b = Engine(dims, max_pos=2048)
+    b.load_state_dict(sd); b.load_rope(); b.finalize()
+    outs = []
+    for e in (a, b):
+        kv = e.kv_alloc(1, 256)
+        first = e.prefill(kv, 0, emb, want_logits=True).clone()
+        steps = [e.decode(kv, [0], want_logits=True).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        outs.append((first, steps, kv.generated(0)))
+        kv.free()
+    assert torch.equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(x, y)
+    assert outs[0][2] == outs[1][2]
+    assert not torch.equal(outs[0][1][0], before)                     # the reload did change the logits
+    # one of the w1 / w3 pair alone cannot be re-interleaved (the other original was released): refused, not silently ignored
+    a.load_weight('language_model.model.layers.0.feed_forward.w1.weight', setup['sd']['language_model.model.layers.0.feed_forward.w1.weight'])
+    with pytest.raises(CalliReaderError):
+        a.finalize()
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize('rows', [1, 2, 3, 4, 5, 7, 8, 9])
 def test_fused_small_batch_decode_gives_the_separate_kernels_bits(setup, rows):
     """Batches of <= 8 rows decode through gemm_decode.hip (RMSNorm prologues, RoPE + cache-write epilogue, residual-add epilogues: six
@@ -284,6 +353,48 @@ def test_prefill_batch_equals_single(setup):
     with pytest.raises(CalliReaderError):
         eng.prefill_batch(kv, [1, 1], [embs[1].cuda(), embs[1].cuda()])
     kv.free()
+
+
+def test_final_layer_on_the_last_rows_only_gives_the_same_bits(setup):
+    """Prefill, final decoder layer: attention / wo / RMSNorm / w1|w3 / w2 run on each page's LAST row only (round-4 verdict, item 3a: nobody reads the
+    other rows; the reference computes them, modeling_internlm2.py:1081-1082); K / V of every row still reach the cache.  CR_PREFILL_LAST_ROWS=0
+    keeps every row.  Logits, the ids of the following decode steps and the final layer's cache rows must be the SAME BITS -- page lengths on both sides
+    of the attention kernel's 32-row waves and 128-row blocks, a batch large enough for the 256x256 GEMM kernel (>= 2048 rows) and single short prompts."""
+    import os
+    from callireader_amd.engine import Engine
+    eng = setup['eng']
+    os.environ['CR_PREFILL_LAST_ROWS'] = '0'
+    try:
+        ref = Engine(setup['dims'], max_pos=2048)
+    finally:
+        del os.environ['CR_PREFILL_LAST_ROWS']
+    ref.share_weights_from(eng)
+    lens = [300, 77, 130, 1500, 33, 32, 64, 65, 1, 129, 128, 97]
+    embs = [prompt(S, 900 + i).cuda() for i, S in enumerate(lens)]
+    assert sum(lens) >= 2048
+    outs = []
+    for e in (eng, ref):
+        kv = e.kv_alloc(len(lens) + 1, 1600)
+        lg_batch = e.prefill_batch(kv, list(range(1, len(lens) + 1)), embs, penalty=1.1, want_logits=True).clone()
+        singles = []
+        kv1 = e.kv_alloc(1, 1600)
+        for x in (embs[4], embs[8], embs[0]):
+            kv1.reset()
+            singles.append(e.prefill(kv1, 0, x, want_logits=True).clone())
+        kv1.free()
+        steps = [e.decode(kv, list(range(1, len(lens) + 1)), penalty=1.1, want_logits=True).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        cache = [kv.read(1, i + 1, lens[i] - 1, which) for i in (0, 3, 8) for which in (0, 1)]        # final layer (of 2), last prompt position
+        outs.append((lg_batch, singles, steps, [kv.generated(i + 1) for i in range(len(lens))], cache))
+        kv.free()
+    a, b = outs
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    for x, y in zip(a[1] + a[2] + a[4], b[1] + b[2] + b[4]):
+        assert torch.equal(x, y)
+    assert a[3] == b[3]
+    # and a page prefilled in the batch equals the same page prefilled alone (both with the shortcut)
+    assert torch.equal(a[0][4], a[1][0]) and torch.equal(a[0][8], a[1][1]) and torch.equal(a[0][0], a[1][2])
+    ref.close()
 
 
 def test_kv_reset_and_limits(setup):

@@ -343,27 +343,28 @@ def test_gemm_skinny_multi_row_tile_path(E):
 
 
 def test_gemm_stream_kernel_gives_the_k_split_kernels_bits(E, monkeypatch):
-    """More than 16 rows at N > 8192, K % 1024 == 0 (w1|w3, the LM head of a decode batch) take gemm_stream.hip: X shared through LDS,
+    """More than 8 rows at N > 8192, K % 2048 == 0 (w1|w3, the LM head of a decode batch) take gemm_stream.hip: X shared through LDS,
     every wave walking the whole K range as the four quarters the K-split kernel gives its four waves, summed in the same order.
-    Its results must equal the K-split kernel's bit for bit -- for the same rows in a small batch (which takes the K-split kernel)
-    and for the same launch with the stream kernel switched off (separate process state: the switch is read once, so the second
-    comparison runs through rows instead) -- and match the reference arithmetic; ragged N (92 553-row vocabulary), every row count class."""
+    Its results must equal the K-split kernel's bit for bit: the reference side sends the same rows in chunks of <= 8, which
+    gemm_stream_supported() refuses, so they really run gemm_skinny.hip's K-split kernel (round-4 advice: chunks of 16 had started to
+    take the stream kernel too) -- and match the reference arithmetic; ragged N (92 553-row vocabulary), every row count class incl. 9 and 16."""
     g = torch.Generator().manual_seed(43)
     N, K = 16400 + 9, 2048
     W = bf(_rand((N, K), g, 0.05)).to(dev())
     bias = bf(_rand((N,), g, 0.1)).to(dev())
-    for M in (17, 33, 64):
+    CH = 8                                                                     # rows per reference launch: <= 8 rows never take the stream kernel
+    for M in (9, 16, 17, 33, 64):
         A = bf(_rand((M, K), g)).to(dev())
         big = E.op_gemm(6, A, W, bias=bias, out_dtype=torch.float32)           # stream kernel
-        small = torch.cat([E.op_gemm(6, A[i:i + 16].contiguous(), W, bias=bias, out_dtype=torch.float32) for i in range(0, M, 16)])   # K-split kernel
+        small = torch.cat([E.op_gemm(6, A[i:i + CH].contiguous(), W, bias=bias, out_dtype=torch.float32) for i in range(0, M, CH)])   # K-split kernel
         torch.cuda.synchronize()
         assert torch.equal(big, small)
         torch.testing.assert_close(big, rb(A.float() @ W.float().t() + bias.float()), rtol=RTOL, atol=2e-2)
         res = bf(_rand((M, N), g)).to(dev())
         o3 = E.op_gemm(3, A, W, bias=bias, res=res)
-        o3s = torch.cat([E.op_gemm(3, A[i:i + 16].contiguous(), W, bias=bias, res=res[i:i + 16].contiguous()) for i in range(0, M, 16)])
+        o3s = torch.cat([E.op_gemm(3, A[i:i + CH].contiguous(), W, bias=bias, res=res[i:i + CH].contiguous()) for i in range(0, M, CH)])
         o0 = E.op_gemm(0, A, W)
-        o0s = torch.cat([E.op_gemm(0, A[i:i + 16].contiguous(), W) for i in range(0, M, 16)])
+        o0s = torch.cat([E.op_gemm(0, A[i:i + CH].contiguous(), W) for i in range(0, M, CH)])
         torch.cuda.synchronize()
         assert torch.equal(o3, o3s) and torch.equal(o0, o0s)
     F, K = 14336, 4096                                                         # w1|w3 itself
@@ -371,7 +372,7 @@ def test_gemm_stream_kernel_gives_the_k_split_kernels_bits(E, monkeypatch):
     Wi = torch.stack([w1.reshape(F // 8, 8, K), w3.reshape(F // 8, 8, K)], dim=1).reshape(2 * F, K).to(dev())
     A = bf(_rand((64, K), g)).to(dev())
     big = E.op_gemm(4, A, Wi)
-    small = torch.cat([E.op_gemm(4, A[i:i + 16].contiguous(), Wi) for i in range(0, 64, 16)])
+    small = torch.cat([E.op_gemm(4, A[i:i + 8].contiguous(), Wi) for i in range(0, 64, 8)])
     torch.cuda.synchronize()
     assert torch.equal(big, small)
     gte, up = rb(A.float() @ w1.float().t().to(dev())), rb(A.float() @ w3.float().t().to(dev()))

@@ -95,6 +95,20 @@ def test_bench_workload_planning_weak_and_strong():
         bench.plan_workload('strong', 64, 4, 8, 0)                                 # fewer pages than ranks
 
 
+def test_bench_strong_share_is_rank_zeros_amount_of_work():
+    """bench.py's `strong_share` (round-4 verdict, item 1) times on ONE GPU what rank 0 of BASELINE config 4 as written has to do: the same number of owned
+    pages and character tiles as plan_workload('strong', 64 pages over 8 ranks, rank 0), laid on pages 0..7 so that the ids compare with the 64-page step's."""
+    import bench
+    sh = bench.plan_strong_share(64, 8)
+    r0 = bench.plan_workload('strong', 64, 64, 8, 0)
+    assert sh['pages_per_gpu'] == r0['pages_per_gpu'] == 8 and sh['ct_hi'] - sh['ct_lo'] == r0['ct_hi'] - r0['ct_lo'] == 768
+    assert sh['mine'] == list(range(8)) and sh['n_pages'] == 8 and sh['ct_lo'] == 0
+    assert sh['ct_hi'] == sh['n_pages'] * bench.CHAR_TILES                        # all_gather_rows at world 1 hands back exactly these rows
+    assert bench.plan_strong_share(64, 4)['pages_per_gpu'] == 16
+    with pytest.raises(ValueError):
+        bench.plan_strong_share(11, 8)                                             # ragged split: the share would not be one rank's work
+
+
 def test_bench_strong_block_flags_parse():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
