@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ModelDesc(C.Structure):
@@ -30,6 +30,8 @@ SIGNATURES = {
     'cr_last_error': (C.c_char_p, []),
     'cr_abi_version': (i32, []),
     'cr_build_id': (C.c_char_p, []),
+    'cr_build_flags': (C.c_char_p, []),
+    'cr_diag_register': (i32, [C.c_char_p]),
     'cr_create': (i32, [i32, C.POINTER(ModelDesc), C.POINTER(vp)]),
     'cr_destroy': (i32, [vp]),
     'cr_load_weight': (i32, [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32, i32, vp]),
@@ -90,6 +92,15 @@ def _load():
         fn.argtypes = args
     if lib.cr_abi_version() != ABI_VERSION:
         raise ImportError(f'ABI version mismatch: library {lib.cr_abi_version()} vs binding {ABI_VERSION}')
+    # diagnostic builds (csrc/diag.hpp: knock-outs, poison, stamps -- several give WRONG RESULTS by design) never load by accident: only when CR_HIP_LIB
+    # names that very file
+    flags = (lib.cr_build_flags() or b'').decode().split()
+    if flags:
+        if not os.environ.get('CR_HIP_LIB'):
+            raise ImportError(f'{_LIB_PATH} is a DIAGNOSTIC build ({" ".join(flags)}): it must not sit at the product\'s path -- rebuild with '
+                              '`python -c "import __graft_entry__ as g; g.build()"`; a variant library is loaded by naming it in CR_HIP_LIB')
+        import sys
+        print(f'[callireader_amd] diagnostic library {_LIB_PATH}: {" ".join(flags)}', file=sys.stderr)
     return lib
 
 

@@ -21,6 +21,10 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'callir
 EXTRA_FLAGS = {'attention.hip': ['-fno-honor-nans', '-fno-slp-vectorize'], 'attention_vit.hip': ['-fno-honor-nans', '-fno-slp-vectorize']}
 
 
+# the product build takes no -D flags: the diagnostic macros of csrc/diag.hpp are reachable through scripts/build_variant.py only
+assert not any(f.startswith('-D') for fl in EXTRA_FLAGS.values() for f in fl), 'callireader_amd/build.py: no -D flags in the product build'
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 

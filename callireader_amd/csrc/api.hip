@@ -130,6 +130,11 @@ int cr_abi_version(void) { return CR_ABI_VERSION; }
 // the literal keeps its "CR_BUILD_ID=" tag so that build.py can find the id in the file without loading it
 const char* cr_build_id(void) { static const char id[] = CR_BUILD_ID; return id + 12; }
 
+// csrc/diag.hpp: translation units compiled with a diagnostic macro announce it here at load time (static constructors); "" for the product build
+static std::string& diag_flags() { static std::string s; return s; }
+int cr_diag_register(const char* flags) { if (flags && *flags) diag_flags() += flags; return 0; }
+const char* cr_build_flags(void) { return diag_flags().c_str(); }
+
 int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     if (!desc || !out) return cr_fail(CR_ERR_ARG, "cr_create: null argument");
     CR_HIP(hipSetDevice(device));

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "attention.hpp"
+#include "diag.hpp"
 
 namespace {
 
@@ -159,6 +160,11 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     // S^T block = K[32 keys] . Q^T: 4 MFMAs
     auto qk32 = [&](const char* kbuf, int kb, const bf16x8* qv) {
         f32x16 s;
+#ifdef CR_KO_VIT_MFMA   // knock-out (wrong results, cost structure only): no matrix-pipe work and no fragment reads -- what the softmax's vector work takes alone
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[e] = bf2f(qv[e & 3][e >> 2]) * (float)(kb + 1) + bf2f(*(const bf16*)(kbuf + (lane & 15) * 2));
+        return s;
+#endif
 #pragma unroll
         for (int e = 0; e < 16; e++) s[e] = 0.f;
 #pragma unroll
@@ -170,6 +176,11 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     };
     // O^T += V^T[32 keys] . P^T: 4 MFMAs; pk = the block's 8 packed bf16 pairs
     auto pv32 = [&](const char* vbuf, int kb, const unsigned* pk, f32x16* o) {
+#ifdef CR_KO_VIT_MFMA
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("" ::"v"(pk[j]));     // the probabilities are computed and dropped
+        return;
+#endif
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const u32x4_t pw = {pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]};
@@ -193,6 +204,11 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     // sweep, and the whole block then repeats the sweep in the exact rescaling form (exact_sweep below).  A per-tile check with an
     // in-loop fallback made hipcc copy the 32 accumulators twice per tile (40 v_mov_b64).
     auto softmax32 = [&](const f32x16& sc, unsigned* pk, float m2f) {
+#ifdef CR_KO_VIT_SOFTMAX   // knock-out (wrong results, cost structure only): no rounding, FMA, exponential or packing -- what the matrix pipe, the fragment reads and the fills take alone
+#pragma unroll
+        for (int j = 0; j < 8; j++) pk[j] = __float_as_uint(sc[2 * j]) ^ __float_as_uint(sc[2 * j + 1]);
+        if (false)
+#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float p0 = __builtin_amdgcn_exp2f(fmaf(rbf1(sc[2 * j]), LOG2E, -m2f));
@@ -209,11 +225,13 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         // the CLS-query partials / attention.hip, sum the fp32 exponentials before rounding: their weights sum to 1 +- 2^-9).  A flagged block is
         // redone AS A WHOLE by the exact kernel, never mixed; both forms sit inside the tests' bound (test_attention_vit_shape: 2 bf16 ulp of
         // the fp32 reference; scripts/attn_bench.py: largest difference between the two kernels 0.0039 on unit-variance data).
+#ifndef CR_KO_VIT_MFMA
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const u32x4_t pw = {pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]};
             lsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, __builtin_bit_cast(bf16x8, pw), lsum, 0, 0, 0);
         }
+#endif
     };
     // the same block in the exact form: running maximum, rescale of O and l when it grows (only exact_sweep uses it)
     auto softmax32_exact = [&](const f32x16& sc, unsigned* pk) {

@@ -63,6 +63,7 @@
 #include <stdlib.h>
 
 #include "gemm_epilogue.hpp"
+#include "diag.hpp"
 
 namespace {
 

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "diag.hpp"
 
 // gemm_stream.hip: X shared through LDS, waves split N (w1|w3, LM head at more than 16 rows); the same fp32 sums as launch_w's four-wave form
 bool gemm_stream_supported(int epi, const GemmParams& p, int splits);

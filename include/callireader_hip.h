@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 8   /* 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8, cr_op_gemm bits 18-19; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 9   /* 9: cr_build_flags, cr_diag_register; 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8, cr_op_gemm bits 18-19; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -51,6 +51,11 @@ int cr_abi_version(void);
 /* sha256 (first 16 hex digits) of the .hip / .hpp sources and of this header the library was compiled from, set by
  * callireader_amd/build.py (-DCR_BUILD_ID): lets a log prove which source tree a run used.  "unknown" for a hand build. */
 const char* cr_build_id(void);
+/* Names of the diagnostic macros any translation unit of this library was compiled with (callireader_amd/csrc/diag.hpp: knock-out / poison / stamp builds
+ * made by scripts/build_variant.py, several of which give wrong results by design), space-separated; "" for the product build.  The ctypes binding refuses a
+ * library that reports any unless CR_HIP_LIB names it explicitly.  cr_diag_register is how such a translation unit announces itself (load time). */
+const char* cr_build_flags(void);
+int cr_diag_register(const char* flags);
 
 /* ---- lifetime & weights --------------------------------------------------------------------- */
 /* InternVLChatModel.__init__ (InternVL/modeling_internvl_chat.py:136-194) */

@@ -80,3 +80,26 @@ def denormalise(x, indices, table, mu, sigma, drop_zero=False, hard_vq=False, co
     s = sigma[fidx].expand(-1, flat.shape[-1])
     m = mu[fidx].expand(-1, flat.shape[-1])
     return flat * s + m, indices
+
+
+def bf16_step(v):
+    """One bf16 step (2^-7 of the binade) at the magnitude of `v`; 0 for v == 0."""
+    import math
+    v = abs(float(v))
+    return 2.0 ** (math.floor(math.log2(v)) - 7) if v > 0 else 0.0
+
+
+def vq_tie_rule(ref_sim_ref_id, ref_sim_other_id, other_sim_ref_id, other_sim_other_id):
+    """THE rule for a cosine-VQ index that differs from the reference's (one function for tests/test_gpu_calli.py, tests/test_gpu_full_depth.py and
+    scripts/real_checkpoint_parity.py; round-4 verdict, item 7).  similarity.py:17-21 takes the arg-max of a bf16 similarity matrix, so index work is
+    exact work and another implementation's index may differ only at a MEASURED tie:
+      (a) the reference's own similarities (the bf16 matrix of similarity.py:19, as floats) at its pick and at the other pick are at most ONE bf16
+          step apart (and ordered: its pick is its maximum), and
+      (b) the other implementation's similarities at the same two rows straddle that gap: its pick scores >= the reference's pick there.
+    `ref_sim_other_id` = None means the other pick is not even among the reference's recorded candidates: no tie.  Returns (ok, gap, step)."""
+    step = bf16_step(ref_sim_ref_id)
+    if ref_sim_other_id is None:
+        return False, float('inf'), step
+    gap = float(ref_sim_ref_id) - float(ref_sim_other_id)
+    ok = 0.0 <= gap <= step and float(other_sim_other_id) >= float(other_sim_ref_id)
+    return ok, gap, step

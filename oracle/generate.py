@@ -59,13 +59,16 @@ def apply_repetition_penalty(scores, generated, penalty):
 def near_tie_straddles(ref_logits, hip_logits, ref_id, hip_id, generated, penalty, atol):
     """The only excuse a differing greedy pick has (checker rule shared by tests/test_gpu_llm.py, tests/test_gpu_full_depth.py and
     __graft_entry__.smoke): the oracle's gap between its pick and the other one, on the PROCESSED scores, must be covered by the logit
-    differences measured at exactly those two ids (the other implementation's scores straddle) and stay inside `atol`.
+    differences measured at exactly those two ids (the other implementation's scores straddle) and stay inside `atol`.  "Straddle" is meant
+    literally (round-4 advice): the other implementation's processed scores must favour ITS pick, sg[hip_id] >= sg[ref_id], i.e.
+    gap <= d_hip - d_ref with the signs -- two shifts in the same direction that leave the oracle's id ahead explain nothing.
     Returns (ok, gap, d_ref_id, d_hip_id)."""
     sc = apply_repetition_penalty(ref_logits.float(), generated, penalty)
     sg = apply_repetition_penalty(hip_logits.float(), generated, penalty)
     gap = float(sc[ref_id] - sc[hip_id])
     d_ref, d_hip = float(sg[ref_id] - sc[ref_id]), float(sg[hip_id] - sc[hip_id])
-    return (gap <= abs(d_ref) + abs(d_hip) + 1e-6 and gap <= atol), gap, d_ref, d_hip
+    straddles = float(sg[hip_id]) >= float(sg[ref_id]) - 1e-6
+    return (straddles and gap <= d_hip - d_ref + 1e-6 and gap <= atol), gap, d_ref, d_hip
 
 
 def greedy_generate(sd, n_layers, inputs_embeds, max_new_tokens=1024, eos_token_id=92542,

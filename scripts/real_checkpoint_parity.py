@@ -126,14 +126,23 @@ def run(model_path, params_dir, image, boxes, question='这幅书法作品内容
                      'resampler_rel_l2': rel_l2(h_rs.float().cpu(), o_rs.float()), 'vq_indices_equal': int(same.sum()), 'vq_indices': int(same.numel()),
                      'pseudo_tokens_rel_l2': rel_l2(h_ref.float().cpu(), o_ref.float())}
     if not bool(same.all()):
-        # the oracle's own cosine gap between its row and HIP's, in bf16 steps of the similarity, at every differing index
+        # every differing index through the ONE VQ rule (oracle/calli_align.py: vq_tie_rule, the tests' rule): the oracle's similarities at the two rows at most
+        # one bf16 step apart AND the HIP tiled GEMM's own similarities (HIP resampler row, normalised table) straddling that gap
+        from callireader_amd import engine as E
         xn = torch.nn.functional.normalize(o_rs, p=2, dim=2)
+        hn = torch.nn.functional.normalize(h_rs.cpu(), p=2, dim=2)
         tn = torch.nn.functional.normalize(sd['normed_emb.weight'], p=2, dim=1)
         diffs = []
         for t, q in (~same).nonzero().tolist():
-            s = torch.matmul(xn[t, q], tn[[int(o_idx[t, q]), int(h_idx.reshape(-1, 3)[t, q])]].t()).float()
-            diffs.append({'tile': t, 'query': q, 'oracle_gap': float(s[0] - s[1]), 'one_bf16_step': bf16_step(s[0])})
+            i_o, i_h = int(o_idx[t, q]), int(h_idx.reshape(-1, 3)[t, q])
+            s = torch.matmul(xn[t, q], tn[[i_o, i_h]].t()).float()
+            rows = torch.stack([tn[i_o], tn[i_h]] + [tn[(i_o + 1 + k) % tn.shape[0]] for k in range(14)])
+            sh = E.op_gemm(0, hn[t, q][None].expand(16, -1).contiguous().cuda(), rows.cuda(), kernel=1).float().cpu()[0]
+            ok, gap, step = calli_align.vq_tie_rule(s[0], s[1], sh[0], sh[1])
+            diffs.append({'tile': t, 'query': q, 'oracle_id': i_o, 'hip_id': i_h, 'oracle_gap': gap, 'one_bf16_step': step,
+                          'hip_similarities': [float(sh[0]), float(sh[1])], 'measured_tie': bool(ok)})
         rep['visual']['vq_differences'] = diffs
+        rep['visual']['vq_differences_all_measured_ties'] = all(d['measured_tie'] for d in diffs)
     log(f"visual stage: page features rel-L2 {rep['visual']['page_features_rel_l2']:.3e}, character features {rep['visual']['char_features_rel_l2']:.3e}, "
         f"resampler {rep['visual']['resampler_rel_l2']:.3e}, VQ indices {rep['visual']['vq_indices_equal']}/{rep['visual']['vq_indices']} equal, "
         f"pseudo tokens {rep['visual']['pseudo_tokens_rel_l2']:.3e}")
@@ -220,6 +229,8 @@ def run(model_path, params_dir, image, boxes, question='这幅书法作品内容
     rep['wall_s'] = round(time.time() - t_all, 1)
     b = rep['bf16']
     status = 0 if (b['identical'] or b.get('at_divergence', {}).get('excusable')) else 1
+    if not rep['visual'].get('vq_differences_all_measured_ties', True):
+        status = 1                                   # a VQ index that differs without a measured tie is a divergence too (vq_tie_rule)
     rep['verdict'] = ('token-exact' if b['identical'] else
                       ('streams part at a measured tie within one bf16 step' if status == 0 else 'DIVERGENCE at a margin the arithmetic cannot excuse'))
     log(f"verdict: {rep['verdict']} (oracle margins: min {rep['oracle']['min_margin']:.4f}, median {rep['oracle']['median_margin']:.4f})")

@@ -46,3 +46,38 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+
+
+def test_diagnostic_builds_are_quarantined(tmp_path):
+    """Round-4 verdict, item 8: the knock-out / poison / stamp blocks inside the product kernels are reachable only through csrc/diag.hpp.
+    (a) the product library reports no diagnostic flags; (b) a diagnostic macro without the variant builder's -DCR_DIAG_BUILD does not compile;
+    (c) a -DCR_KO_EPI library (scripts/build_variant.py: wrong results by design) reports its flag, carries another build id than the product, and
+    placed at the product's default path it FAILS TO LOAD with a clear message; named explicitly in CR_HIP_LIB it loads (the A/B route)."""
+    import shutil
+    import subprocess
+    import sys
+    from callireader_amd import build, _binding as B
+    assert B.lib.cr_build_flags() == b''
+    csrc = os.path.join(ROOT, 'callireader_amd', 'csrc')
+    r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-std=c++17', '-DCR_KO_XFRAG=1', '-E', os.path.join(csrc, 'gemm_skinny.hip'), '-o', os.devnull],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode != 0 and b'build_variant.py' in r.stdout
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'build_variant.py'), 'ko_quarantine_test', 'gemm_skinny.hip', '-DCR_KO_XFRAG=1'],
+                          stdout=subprocess.DEVNULL)
+    variant = os.path.join(ROOT, 'ab', 'libko_quarantine_test.so')
+    blob = open(variant, 'rb').read()
+    i = blob.find(b'CR_BUILD_ID=')
+    assert i >= 0 and blob[i + 12:i + 28].decode() != build.source_hash()
+    # a copy of the package whose DEFAULT library is the variant
+    pkg = tmp_path / 'callireader_amd'
+    (pkg / 'csrc').mkdir(parents=True)
+    for f in os.listdir(os.path.join(ROOT, 'callireader_amd')):
+        if f.endswith('.py'):
+            shutil.copy(os.path.join(ROOT, 'callireader_amd', f), pkg / f)
+    shutil.copy(variant, pkg / 'csrc' / 'libcallireader_hip.so')
+    env = {k: v for k, v in os.environ.items() if k != 'CR_HIP_LIB'}
+    code = 'import sys; sys.path.insert(0, sys.argv[1]); import callireader_amd._binding as B; print(B.lib.cr_build_flags().decode())'
+    r = subprocess.run([sys.executable, '-c', code, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path))
+    assert r.returncode != 0 and b'DIAGNOSTIC build (CR_KO_XFRAG)' in r.stderr, r.stderr[-400:]
+    r = subprocess.run([sys.executable, '-c', code, str(tmp_path)], env=dict(env, CR_HIP_LIB=variant), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.strip() == b'CR_KO_XFRAG' and b'diagnostic library' in r.stderr, r.stderr[-400:]

@@ -63,6 +63,14 @@ def test_tile_results_do_not_depend_on_the_batch(setup):
     assert torch.equal(torch.cat([eng.denorm(whole[i:i + 7], idx[i:i + 7]) for i in range(0, 30, 7)]), back)
 
 
+def hip_similarities(E, x_row_normalised, table_normalised, i_ref, i_hip):
+    """The HIP tiled GEMM's own similarities of one normalised query row against the reference's and the HIP path's table rows: (at i_ref, at i_hip)."""
+    tn = table_normalised
+    rows = torch.stack([tn[i_ref], tn[i_hip]] + [tn[(i_ref + 1 + k) % tn.shape[0]] for k in range(14)])     # 16 table rows, the two candidates first
+    s = E.op_gemm(0, x_row_normalised[None].expand(16, -1).contiguous().cuda(), rows.cuda(), kernel=1).float().cpu()[0]
+    return float(s[0]), float(s[1])
+
+
 def test_vq_planted_and_random(setup):
     o, sd = setup['oracle'], setup['sd']
     table = sd['normed_emb.weight']
@@ -78,10 +86,10 @@ def test_vq_planted_and_random(setup):
     assert int(idx[0, 0]) == 123 and int(idx[1, 2]) == 5002 and int(idx[2, 1]) == 0
     # cosine of the planted rows is ~1 on both sides; elsewhere the max cosine must agree to bf16 resolution
     assert torch.allclose(cos, rcos.float(), atol=8e-3)
-    # Index work is exact work (round-3 verdict): an index may differ from the oracle's only at a MEASURED tie.  sim = the oracle's own
-    # bf16 similarity matrix (similarity.py:17-19).  Where the oracle's top-2 gap exceeds 2^-7 the indices must be equal outright; a
-    # differing index passes only if the oracle's gap between the two rows is at most ONE bf16 step of the similarity there AND the HIP
-    # GEMM's own similarities at those two rows (the tiled kernel on the same normalised operands) straddle it: HIP's pick >= the oracle's.
+    # Index work is exact work (round-3 verdict): an index may differ from the oracle's only at a MEASURED tie -- oracle/calli_align.py: vq_tie_rule, the ONE
+    # rule shared with tests/test_gpu_full_depth.py and scripts/real_checkpoint_parity.py.  sim = the oracle's own bf16 similarity matrix (similarity.py:17-19).
+    # Where the oracle's top-2 gap exceeds 2^-7 the indices must be equal outright; the HIP similarities at the two rows come from the tiled kernel on the
+    # same normalised operands.
     from callireader_amd import engine as E
     xn = torch.nn.functional.normalize(q, p=2, dim=2)
     tn = torch.nn.functional.normalize(table, p=2, dim=1)
@@ -96,14 +104,10 @@ def test_vq_planted_and_random(setup):
                 continue
             n_diff += 1
             assert float(top2[b, j, 0] - top2[b, j, 1]) <= 2.0 ** -7, (b, j, 'the oracle has a clear maximum here')
-            v = float(sim[b, j, i_o])
-            gap = v - float(sim[b, j, i_h])
-            ulp = 2.0 ** (math.floor(math.log2(abs(v))) - 7) if v != 0 else 0.0
-            assert 0.0 <= gap <= ulp, (b, j, i_h, i_o, gap, ulp)
-            rows = torch.stack([tn[i_o], tn[i_h]] + [tn[(i_o + 1 + k) % tn.shape[0]] for k in range(14)])     # 16 table rows, the two candidates first
-            s_hip = E.op_gemm(0, flat_x[b * idx.shape[1] + j][None].expand(16, -1).contiguous().cuda(), rows.cuda(), kernel=1).float().cpu()[0]
-            print(f'  VQ ({b},{j}): HIP {i_h} vs oracle {i_o}: oracle gap {gap:.3e} (one step {ulp:.3e}); HIP similarities {float(s_hip[1]):.6f} / {float(s_hip[0]):.6f}')
-            assert float(s_hip[1]) >= float(s_hip[0]), (b, j, 'the HIP similarities do not straddle the oracle\'s gap')
+            s_hip = hip_similarities(E, flat_x[b * idx.shape[1] + j], tn, i_o, i_h)
+            ok, gap, step = o.vq_tie_rule(sim[b, j, i_o], sim[b, j, i_h], s_hip[0], s_hip[1])
+            print(f'  VQ ({b},{j}): HIP {i_h} vs oracle {i_o}: oracle gap {gap:.3e} (one step {step:.3e}); HIP similarities {s_hip[1]:.6f} / {s_hip[0]:.6f}')
+            assert ok, (b, j, i_h, i_o, gap, step, s_hip)
     print(f'VQ: {n_diff} of {idx.numel()} indices differ from the oracle, all at measured ties')
 
 

@@ -329,7 +329,24 @@ def test_config1_example_page_end_to_end_vs_reference(gold, engine):
     gap = (gap[..., 0] - gap[..., 1]).reshape(-1)
     neq = (idx.cpu().reshape(-1) != ref_idx.reshape(-1))
     out['vq'] = {'rows': int(neq.numel()), 'equal': int((~neq).sum()), 'reference_top2_gap_min': float(gap.min()),
-                 'largest_reference_gap_where_different': float(gap[neq].max()) if neq.any() else 0.0}
+                 'largest_reference_gap_where_different': float(gap[neq].max()) if neq.any() else 0.0, 'differing': []}
+    if neq.any():
+        # the ONE rule for a differing VQ index (oracle/calli_align.py: vq_tie_rule, shared with tests/test_gpu_calli.py and scripts/real_checkpoint_parity.py):
+        # the reference's similarities at the two rows (its recorded top-8 candidates, vq.top8_*) at most one bf16 step apart AND the HIP tiled GEMM's own
+        # similarities, on the HIP path's resampler row and the normalised table, straddling that gap
+        from oracle import calli_align
+        from callireader_amd import engine as E, synthetic
+        from test_gpu_calli import hip_similarities
+        top_ids, top_cos = torch.from_numpy(g1['vq.top8_ids']).reshape(-1, 8), torch.from_numpy(g1['vq.top8_cos']).reshape(-1, 8)
+        table = synthetic.make_state_dict(ModelDims.full(), parts=('vq',), seed=0)['normed_emb.weight']
+        tn = torch.nn.functional.normalize(table, p=2, dim=1)
+        xn = torch.nn.functional.normalize(rs.cpu().reshape(-1, rs.shape[-1]), p=2, dim=1)
+        for r in neq.nonzero().reshape(-1).tolist():
+            i_o, i_h = int(ref_idx.reshape(-1)[r]), int(idx.cpu().reshape(-1)[r])
+            cand = dict(zip(top_ids[r].tolist(), top_cos[r].tolist()))
+            s_hip = hip_similarities(E, xn[r], tn, i_o, i_h)
+            ok, vgap, step = calli_align.vq_tie_rule(cand[i_o], cand.get(i_h), s_hip[0], s_hip[1])
+            out['vq']['differing'].append({'row': r, 'ref_id': i_o, 'hip_id': i_h, 'reference_gap': vgap, 'one_bf16_step': step, 'hip_similarities': s_hip, 'measured_tie': ok})
 
     ids = torch.from_numpy(g1['input_ids'])
     assert int((ids == 92546).sum()) == 11 * 256 and int((ids == 92537).sum()) == back.numel() // 4096
@@ -362,8 +379,8 @@ def test_config1_example_page_end_to_end_vs_reference(gold, engine):
         assert out[name]['rel_l2'] <= noise_vit, (name, out[name])
     # the resampler adds 4 bf16 layers on top of the visual features; the pseudo tokens are its output times sigma plus mu
     assert out['resampler']['rel_l2'] <= 2 * noise_vit and out['pseudo']['rel_l2'] <= 2 * noise_vit, out
-    # VQ: equal, or the reference's own best two cosines sit within 4 bf16 steps of each other (0.002 at cos ~ 0.07)
-    assert out['vq']['largest_reference_gap_where_different'] <= 0.002, out['vq']
+    # VQ: equal, or a measured tie by the one rule (vq_tie_rule) -- round 4 accepted any differing index whose reference top-2 gap was <= 0.002
+    assert all(d['measured_tie'] for d in out['vq']['differing']), out['vq']
     for t, r in enumerate(rows):
         assert r['rel_l2_stride8'] <= noise_llm, (t, r)
         if r['ref_id'] != r['hip_id']:

@@ -72,3 +72,26 @@ def test_transform_values():
 def test_boxes_from_labelme():
     data = {'imageHeight': 2000, 'imageWidth': 788, 'shapes': [{'points': [[0.1, 0.2], [0.3, 0.4]]}, {'points': [[-0.1, 0.5], [1.2, 0.9]]}]}
     assert preprocess.boxes_from_labelme(data) == [(78, 400, 236, 800), (0, 1000, 788, 1800)]
+
+
+def test_tie_rules_of_the_checker():
+    """The two excuses a differing index has are single functions in oracle/ (round-4 verdict item 7, advice): a greedy pick (near_tie_straddles) and a
+    cosine-VQ index (vq_tie_rule).  Both demand a MEASURED straddle, not a bound."""
+    import torch
+    from oracle.generate import near_tie_straddles
+    from oracle.calli_align import vq_tie_rule, bf16_step
+    ref = torch.zeros(10); ref[3], ref[7] = 5.00, 4.92                  # the oracle picks 3, gap 0.08
+    hip = ref.clone(); hip[3], hip[7] = 4.97, 5.01                       # HIP's scores favour 7: a straddle
+    ok, gap, d_ref, d_hip = near_tie_straddles(ref, hip, 3, 7, [], 1.0, 0.12)
+    assert ok and abs(gap - 0.08) < 1e-6 and d_ref < 0 < d_hip
+    hip2 = ref.clone(); hip2[3], hip2[7] = 5.05, 4.97                    # both shifted up by 0.05: |d| sums to 0.10 >= gap, but 3 is still ahead
+    assert not near_tie_straddles(ref, hip2, 3, 7, [], 1.0, 0.12)[0]
+    assert not near_tie_straddles(ref, hip, 3, 7, [], 1.0, 0.05)[0]      # outside the tolerance
+    # repetition penalty is applied to both sides before anything is compared
+    ok, gap, _, _ = near_tie_straddles(ref, hip, 3, 7, [3], 1.5, 0.12)
+    assert gap < 0                                                       # the penalty already puts 7 ahead for the oracle: not this rule's case, but consistent
+    assert bf16_step(0.07) == 2.0 ** -11 and bf16_step(1.0) == 2.0 ** -7 and bf16_step(0.0) == 0.0
+    assert vq_tie_rule(0.0703125, 0.0703125 - 2.0 ** -11, 0.0700, 0.0701)[0]            # one step apart, HIP straddles
+    assert not vq_tie_rule(0.0703125, 0.0703125 - 2.0 ** -10, 0.0700, 0.0701)[0]        # two steps apart
+    assert not vq_tie_rule(0.0703125, 0.0703125 - 2.0 ** -11, 0.0702, 0.0701)[0]        # HIP's own similarities favour the reference's row
+    assert not vq_tie_rule(0.0703125, None, 0.0700, 0.0701)[0]                          # not among the reference's candidates
