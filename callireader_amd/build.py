@@ -18,7 +18,7 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'callir
 # without the assumption every fmaxf on an accumulator costs an extra canonicalising v_max_f32
 # attention_vit.hip, -fno-slp-vectorize: the SLP pass packs the row-sum adds into v_pk_add_f32, which issue slower beside MFMAs than the
 # plain adds they replace (guide: 'packed f32 VALU ... an anti-lever beside MFMAs'): 1.453 -> 1.432 ms per 255-tile launch, same bits
-EXTRA_FLAGS = {'attention.hip': ['-fno-honor-nans', '-fno-slp-vectorize'], 'attention_vit.hip': ['-fno-honor-nans', '-fno-slp-vectorize']}
+EXTRA_FLAGS = {'attention.hip': ['-fno-honor-nans', '-fno-slp-vectorize'], 'attention_vit.hip': ['-fno-honor-nans', '-fno-slp-vectorize']}      # (attention_decode.hip compares with -inf on purpose: default flags)
 
 
 # the product build takes no -D flags: the diagnostic macros of csrc/diag.hpp are reachable through scripts/build_variant.py only

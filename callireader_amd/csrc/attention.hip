@@ -432,6 +432,11 @@ int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t strea
     if (p.Sq <= 0 || p.Sq > 32 || p.H <= 0 || p.B <= 0 || p.nsplit <= 0 || !p.part_ml || !p.part_o) return CR_ERR_ARG;
     if ((p.q_rs & 7) || (p.k_rs & 7) || (p.v_rs & 7)) return CR_ERR_ARG;
     const bool dv = p.s_div != 1.0f;
+    if (decode_attn_supported(p, head_dim)) {                 // attention_decode.hip writes the same partials; the combine is this file's
+        if (launch_decode_attn(p, stream) != CR_OK) return CR_ERR_HIP;
+        hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(p.Sq, p.H, p.B), dim3(128), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+    }
     if (head_dim == 64) return dv ? launch_split_d<64, true>(p, stream) : launch_split_d<64, false>(p, stream);
     if (head_dim == 128) return dv ? launch_split_d<128, true>(p, stream) : launch_split_d<128, false>(p, stream);
     return CR_ERR_ARG;

@@ -33,6 +33,10 @@ int launch_flash_attn(const AttnParams& p, int head_dim, bool causal, hipStream_
 // decode: Sq <= 32 query rows per (batch, head), non-causal over each sequence's own keys, split over the keys
 int launch_flash_attn_split(const AttnParams& p, int head_dim, hipStream_t stream);
 size_t attn_split_ws_floats(int B, int H, int Sq, int nsplit, int head_dim);
+// attention_decode.hip: the split half of launch_flash_attn_split as a streaming vector-pipe kernel (d = 128, 4 query rows per (batch, head): InternLM2's GQA
+// group); launch_flash_attn_split takes it by itself when the shape qualifies (CR_DECODE_ATTN=0: the matrix-core split kernel)
+bool decode_attn_supported(const AttnParams& p, int head_dim);
+int launch_decode_attn(const AttnParams& p, hipStream_t stream);
 
 // ViT layout (S = 1 + 128 n tokens, d = 64, no mask): attention_vit.hip.  launch_flash_attn takes this path by itself when
 // p.part_ml points at vit_attn_ws_floats(B, H, S) floats of scratch (the CLS query's partials) and the shape qualifies.

@@ -59,11 +59,11 @@ class InternVLChatModel:
         return m
 
     @classmethod
-    def from_synthetic(cls, dims=None, seed=0, parts=('vit', 'mlp1', 'resampler', 'vq', 'llm'), **kw):
-        """Seeded random weights of the checkpoint's architecture, drawn on the GPU tensor by tensor."""
+    def from_synthetic(cls, dims=None, seed=0, parts=('vit', 'mlp1', 'resampler', 'vq', 'llm'), outlier_shift=0, **kw):
+        """Seeded random weights of the checkpoint's architecture, drawn on the GPU tensor by tensor (outlier_shift: synthetic.outlier_transform)."""
         from . import synthetic
         m = cls(dims, **kw)
-        for k, v in synthetic.iter_state_dict(m.dims, parts=parts, seed=seed, device=m.device):
+        for k, v in synthetic.iter_state_dict(m.dims, parts=parts, seed=seed, device=m.device, outlier_shift=outlier_shift):
             m.engine.load_weight(k, v)
             del v
         m._finish()

@@ -151,15 +151,59 @@ def make_tensor(name, spec, seed=0, device='cpu', dtype=torch.bfloat16):
 
 
 def make_state_dict(dims: ModelDims, parts=('vit', 'mlp1', 'resampler', 'vq', 'llm'),
-                    seed=0, device='cpu', dtype=torch.bfloat16):
+                    seed=0, device='cpu', dtype=torch.bfloat16, outlier_shift=0):
     """Full dict.  For the 7.7 B-parameter LLM prefer `iter_state_dict` (streams)."""
-    return {k: make_tensor(k, s, seed, device, dtype) for k, s in key_specs(dims, parts).items()}
+    return {k: outlier_transform(k, make_tensor(k, s, seed, device, dtype), dims, outlier_shift) for k, s in key_specs(dims, parts).items()}
 
 
 def iter_state_dict(dims: ModelDims, parts=('vit', 'mlp1', 'resampler', 'vq', 'llm'),
-                    seed=0, device='cpu', dtype=torch.bfloat16):
+                    seed=0, device='cpu', dtype=torch.bfloat16, outlier_shift=0):
     for k, s in key_specs(dims, parts).items():
-        yield k, make_tensor(k, s, seed, device, dtype)
+        yield k, outlier_transform(k, make_tensor(k, s, seed, device, dtype), dims, outlier_shift)
+
+
+# ---- "outlier" checkpoints: the SAME function with the channel / row statistics real checkpoints have ---------------------------------------------
+# Random-Gaussian weights have no outlier channels, so they cannot tell a good fp8 scaling scheme from a bad one (round-4 verdict, item 4a).  Real LLM / ViT
+# checkpoints do: a few normalised-activation channels carry values tens to hundreds of times the rest (large norm gains against small consuming weight
+# columns), and some weight rows are far larger than others.  This variant re-scales the seed-0 tensors by POWERS OF TWO in matched pairs:
+#   * norm gain (and LayerNorm bias) of a few channels x 2^shift, the consuming linear's columns of those channels x 2^-shift:
+#       LLM attention_norm -> wqkv, ffn_norm -> w1 / w3, final norm -> output; ViT norm1 -> qkv, norm2 -> fc1; mlp1.0 -> mlp1.1;
+#   * every OUTLIER['w3_rows_every']-th row of w3 (the linear branch of SwiGLU) x 2^shift, the matching w2 columns x 2^-shift: outlier channels in w2's INPUT.
+# A power-of-two factor commutes with every bf16 / fp32 rounding (no overflow or underflow at these magnitudes), so the network's function is unchanged BIT FOR
+# BIT in the reference's bf16 arithmetic -- tests/golden/full_depth.npz, generated by the reference on the plain checkpoint, is also the golden of every
+# outlier variant (tests/test_oracle_golden.py checks the oracle on both, tests/test_gpu_fp8_mfma.py the HIP bf16 path) -- while every row-wise maximum an
+# fp8 quantiser takes is now dominated by the outlier channels (x 32 at shift 5, x 1024 at shift 10).
+OUTLIER = dict(llm_channels=(5, 700, 1403, 2222, 3071, 4000), vit_channels=(3, 257, 640, 1001), w3_rows_every=1021)
+
+
+def outlier_transform(name, t, dims: ModelDims, shift, cfg=OUTLIER):
+    """`t` (a tensor of the plain checkpoint under key `name`) -> the outlier variant's tensor; shift = 0 returns `t` itself."""
+    if not shift:
+        return t
+    up, dn = 2.0 ** shift, 2.0 ** -shift
+    lc = torch.tensor(cfg['llm_channels'], device=t.device)
+    vc = torch.tensor(cfg['vit_channels'], device=t.device)
+    t = t.clone()
+    if name.startswith('language_model.'):
+        if name.endswith('attention_norm.weight') or name.endswith('ffn_norm.weight') or name == 'language_model.model.norm.weight':
+            t[lc] *= up
+        elif name.endswith('attention.wqkv.weight') or name.endswith('feed_forward.w1.weight') or name == 'language_model.output.weight':
+            t[:, lc] *= dn
+        elif name.endswith('feed_forward.w3.weight'):
+            t[:, lc] *= dn
+            t[::cfg['w3_rows_every']] *= up
+        elif name.endswith('feed_forward.w2.weight'):
+            t[:, ::cfg['w3_rows_every']] *= dn
+    elif name.startswith('vision_model.encoder.layers.'):
+        if name.endswith(('norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias')):
+            t[vc] *= up
+        elif name.endswith('attn.qkv.weight') or name.endswith('mlp.fc1.weight'):
+            t[:, vc] *= dn
+    elif name in ('mlp1.0.weight', 'mlp1.0.bias'):
+        t[lc] *= up
+    elif name == 'mlp1.1.weight':
+        t[:, lc] *= dn
+    return t
 
 
 def make_pixels(n_tiles, seed=0, device='cpu', dtype=torch.bfloat16, size=448):

@@ -63,14 +63,14 @@ def check_near_tie(where, got, ref_id, hip_id, ref_logit_of, noise_abs):
     d_ref, d_hip = float(got[ref_id]) - ref_logit_of[ref_id], float(got[hip_id]) - ref_logit_of[hip_id]
     rec = {'gap': gap, 'd_ref_id': d_ref, 'd_hip_id': d_hip}
     print(f'  {where}: pick differs: reference gap {gap:.4f}, measured d(ref id) {d_ref:+.4f}, d(hip id) {d_hip:+.4f}')
-    assert gap <= abs(d_ref) + abs(d_hip) + 1e-6, (where, rec)
+    assert gap <= d_hip - d_ref + 1e-6, (where, rec)            # a literal straddle (oracle/generate.py: near_tie_straddles), signs and all
     assert max(abs(d_ref), abs(d_hip)) <= noise_abs, (where, rec)
     assert gap <= TIE_CAP, (where, rec)
     return rec
 
 
 def _dump():
-    for d in (os.path.join(ROOT, 'profiles', 'round4'), os.path.join(ROOT, 'gpurun_out')):
+    for d in (os.path.join(ROOT, 'profiles', 'round5'), os.path.join(ROOT, 'gpurun_out')):
         try:
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, 'full_depth_parity.json'), 'w') as f:

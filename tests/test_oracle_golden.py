@@ -201,3 +201,26 @@ def test_repetition_penalty_rule_matches_installed_transformers():
             if penalty != 1.0 else scores.clone()
         got = apply_repetition_penalty(scores.clone(), generated, penalty)
         assert torch.equal(got, want)
+
+
+def test_outlier_checkpoints_are_the_same_function_bit_for_bit():
+    """callireader_amd/synthetic.py: outlier_transform -- power-of-two re-scaling of matched norm-gain / weight-column pairs (and w3 rows / w2 columns).  It
+    commutes with every rounding of the reference's bf16 arithmetic, so the oracle (pinned to the reference at atol 0 above) must return the SAME BITS on the
+    plain and on the outlier checkpoints: that is what makes tests/golden/full_depth.npz the golden of every variant (scripts/fp8_schemes.py)."""
+    from callireader_amd.config import ModelDims
+    from callireader_amd import synthetic
+    from oracle import internlm2, vision
+    dims = ModelDims.reduced(vit_layers=1, llm_layers=2, rs_depth=1, vocab=2048)
+    emb = (torch.randn(1, 24, 4096, generator=torch.Generator().manual_seed(3)) * 0.02).to(torch.bfloat16)
+    px = synthetic.make_pixels(1, seed=1)
+    outs = []
+    for shift in (0, 5, 10):
+        sd = synthetic.make_state_dict(dims, parts=('vit', 'mlp1', 'llm'), seed=0, outlier_shift=shift)
+        with torch.no_grad():
+            outs.append((internlm2.model_forward(sd, 2, inputs_embeds=emb, all_logits=False)[0], vision.extract_feature(sd, px, 1)))
+        if shift:
+            k = 'language_model.model.layers.0.attention_norm.weight'
+            plain = synthetic.make_state_dict(dims, parts=('llm',), seed=0)[k]
+            assert float((sd[k].float() / plain.float()).max()) == 2.0 ** shift           # the outliers are really there
+    for lg, ft in outs[1:]:
+        assert torch.equal(lg, outs[0][0]) and torch.equal(ft, outs[0][1])
