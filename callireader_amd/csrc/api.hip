@@ -210,7 +210,7 @@ int cr_load_weight(cr_ctx* c, const char* name, const void* src, int dtype, cons
     // serving the OLD values to the kernels that read them (round-4 advice): they go now, cr_finalize rebuilds the decode layout, and the fp8
     // options switch off until cr_enable_fp8_* is called again (it rebuilds what is missing)
     bool had_fp8 = false;
-    for (const char* pre : {"declayout.", "fp8.", "fp8s.", "fp8b."}) {
+    for (const char* pre : {"declayout.", "fp8.", "fp8s.", "fp8b.", "fp8dl."}) {
         auto d = c->w.find(std::string(pre) + name);
         if (d == c->w.end()) continue;
         if (pre[0] == 'f') had_fp8 = true;
@@ -328,7 +328,9 @@ int cr_op_decode_gemm(int which, int flags, const void* W, int64_t ldw, int M, i
 }
 
 int cr_op_decode_swizzle(int which, const void* W, int64_t ldw, int N, int K, void* dst, void* stream) {
-    const int r = decode_swizzle_weight(which, (const bf16*)W, ldw, N, K, (bf16*)dst, (hipStream_t)stream);
+    // which = 8: e4m3 bytes [N][ldw] (cr_enable_fp8_decode's copies; K % 64 == 0), else bf16 for op_decode_gemm's `which`
+    const int r = which == 8 ? decode_swizzle_weight8((const unsigned char*)W, ldw, N, K, (unsigned char*)dst, (hipStream_t)stream)
+                             : decode_swizzle_weight(which, (const bf16*)W, ldw, N, K, (bf16*)dst, (hipStream_t)stream);
     if (r != CR_OK) return cr_fail(r, "cr_op_decode_swizzle(which=%d, N=%d, K=%d) rejected or failed to launch", which, N, K);
     return CR_OK;
 }

@@ -33,3 +33,6 @@ int launch_decode_gemm(int which, const DecodeGemmParams& p, hipStream_t stream)
 // the decode layout of one of the five weights (DEC_WQKV bakes the RoPE tile order in): `dst` holds decode_swizzled_bytes(N, K)
 size_t decode_swizzled_bytes(int N, int K);
 int decode_swizzle_weight(int which, const bf16* W, int64_t ldw, int N, int K, bf16* dst, hipStream_t stream);
+// the e4m3 copies of cr_enable_fp8_decode in their decode layout (1 KiB per 16-row tile and 64-deep k-step): gemm_skinny.hip's W8 instances with GemmParams::wsw = 1
+size_t decode_swizzled8_bytes(int N, int K);
+int decode_swizzle_weight8(const unsigned char* W, int64_t ldw, int N, int K, unsigned char* dst, hipStream_t stream);

@@ -10,7 +10,7 @@
 //   * scripts/build_variant.py also hashes the flags into cr_build_id(), so a variant never carries the product's id.
 #pragma once
 
-#define CR_DIAG_WRONG_RESULTS_LIST "CR_BREAK_WAIT CR_KO_STORE CR_KO_WCONTIG CR_KO_AROWS CR_KO_EPI CR_KO_XFRAG CR_KO_W8CONTIG CR_KO_VIT_SOFTMAX CR_KO_VIT_MFMA"
+#define CR_DIAG_WRONG_RESULTS_LIST "CR_BREAK_WAIT CR_KO_STORE CR_KO_WCONTIG CR_KO_AROWS CR_KO_EPI CR_KO_XFRAG CR_KO_VIT_SOFTMAX CR_KO_VIT_MFMA"
 
 #ifdef CR_BREAK_WAIT
 #define CR_DIAG_S1 "CR_BREAK_WAIT "
@@ -42,10 +42,10 @@
 #else
 #define CR_DIAG_S6 ""
 #endif
-#ifdef CR_KO_W8CONTIG
-#define CR_DIAG_S7 "CR_KO_W8CONTIG "
+#ifdef CR_TILE_GM
+#define CR_DIAG_S7 "CR_TILE_GM "
 #else
-#define CR_DIAG_S7 ""
+#define CR_DIAG_S7 ""      /* (round 4's CR_KO_W8CONTIG became the e4m3 copies' decode layout) */
 #endif
 #ifdef CR_POISON
 #define CR_DIAG_S8 "CR_POISON "
@@ -74,7 +74,7 @@
 #endif
 
 #if defined(CR_BREAK_WAIT) || defined(CR_KO_STORE) || defined(CR_KO_WCONTIG) || defined(CR_KO_AROWS) || defined(CR_KO_EPI) || defined(CR_KO_XFRAG) || \
-    defined(CR_KO_W8CONTIG) || defined(CR_POISON) || defined(CR_KI_VALU) || defined(CR_DIAG_STAMPS) || defined(CR_KO_VIT_SOFTMAX) || defined(CR_KO_VIT_MFMA)
+    defined(CR_POISON) || defined(CR_KI_VALU) || defined(CR_DIAG_STAMPS) || defined(CR_KO_VIT_SOFTMAX) || defined(CR_KO_VIT_MFMA) || defined(CR_TILE_GM)
 #ifndef CR_DIAG_BUILD
 #error "diagnostic macros (CR_KO_*, CR_KI_VALU, CR_POISON, CR_BREAK_WAIT, CR_DIAG_STAMPS) are only available through scripts/build_variant.py (-DCR_DIAG_BUILD): csrc/diag.hpp"
 #endif

@@ -144,8 +144,8 @@ int launch_gemm_tail(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return CR_ERR_ARG;
     if ((p.lda & 7) || (p.ldw & 7)) return CR_ERR_ARG;
-    if (p.wsw) {                                                 // decode-layout weights: the weight-streaming kernels only (M <= 64, bf16)
-        if (p.w8 || p.a8 || p.wsw > 2 || (p.wsw == 2 && epi != EPI_PARTIAL) || ((uintptr_t)p.W & 15) || !gemm_skinny_supported(epi, p)) return CR_ERR_ARG;
+    if (p.wsw) {                                                 // decode-layout weights: the weight-streaming kernels only (M <= 64; bf16, or e4m3 in plain tile order)
+        if ((p.w8 && p.wsw != 1) || p.a8 || p.wsw > 2 || (p.wsw == 2 && epi != EPI_PARTIAL) || ((uintptr_t)p.W & 15) || !gemm_skinny_supported(epi, p)) return CR_ERR_ARG;
         return launch_gemm_skinny(epi, p, stream);
     }
     if (p.a8) return launch_gemm256_f8(epi, p, stream);                                                  // e4m3 x e4m3 on the matrix cores

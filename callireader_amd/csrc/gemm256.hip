@@ -518,7 +518,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     auto tile_origin = [&](int orig, int& m0, int& n0) {
         const int xcd = orig & 7, q = ntiles >> 3, r = ntiles & 7;
         const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+#ifdef CR_TILE_GM       // diagnostic (scripts/traffic_clock.py): another super-group height -- right results, other operand traffic (1: row-major tile order)
+        constexpr int GM = CR_TILE_GM;
+#else
         constexpr int GM = 8;
+#endif
         const int per_group = GM * ntn;
         const int grp = pid / per_group;
         const int first_m = grp * GM;

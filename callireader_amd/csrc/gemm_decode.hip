@@ -268,6 +268,20 @@ __global__ __launch_bounds__(256) void decode_swizzle_kernel(const bf16* __restr
     *(bf16x8*)(dst + (blk * 64 + lane) * 8) = *(const bf16x8*)(W + (int64_t)row * ldw + ks * 32 + (lane >> 4) * 8);
 }
 
+// The same for the e4m3 copies of cr_enable_fp8_decode (gemm_skinny.hip's W8 instances walk K in 64-deep steps, 16 bytes per lane): one 1 KiB block per
+// (16-row tile, 64-deep k-step), dst[((tile * K/64 + kstep) * 64 + lane) * 16 + e] = W8[min(tile * 16 + (lane & 15), N - 1)][kstep * 64 + (lane >> 4) * 16 + e].
+__global__ __launch_bounds__(256) void decode_swizzle8_kernel(const unsigned char* __restrict__ W, int64_t ldw, int N, int K, unsigned char* __restrict__ dst) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const int ksteps = K / 64;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (N + 15) / 16;
+    if (blk >= ntiles * ksteps) return;
+    const int tile = (int)(blk / ksteps), ks = (int)(blk % ksteps);
+    const int row = min(tile * 16 + (lane & 15), N - 1);
+    *(u32x4_t*)(dst + (blk * 64 + lane) * 16) = *(const u32x4_t*)(W + (int64_t)row * ldw + ks * 64 + (lane >> 4) * 16);
+}
+
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -295,6 +309,15 @@ int decode_swizzle_weight(int which, const bf16* W, int64_t ldw, int N, int K, b
     const unsigned grid = (unsigned)((blocks + 3) / 4);
     if (which == DEC_WQKV) hipLaunchKernelGGL(decode_swizzle_kernel<true>, dim3(grid), dim3(256), 0, st, W, ldw, N, K, dst);
     else hipLaunchKernelGGL(decode_swizzle_kernel<false>, dim3(grid), dim3(256), 0, st, W, ldw, N, K, dst);
+    return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+size_t decode_swizzled8_bytes(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K; }
+
+int decode_swizzle_weight8(const unsigned char* W, int64_t ldw, int N, int K, unsigned char* dst, hipStream_t st) {
+    if (!W || !dst || N <= 0 || K <= 0 || (K & 63) || (ldw & 15)) return CR_ERR_ARG;
+    const int64_t blocks = (int64_t)((N + 15) / 16) * (K / 64);
+    hipLaunchKernelGGL(decode_swizzle8_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, W, ldw, N, K, dst);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 

@@ -87,13 +87,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmParam
         const unsigned char* w8p[RT];
 #pragma unroll
         for (int r = 0; r < RT; r++) w8p[r] = (const unsigned char*)p.W + (int64_t)min(n0 + r * 16 + (lane & 15), p.N - 1) * p.ldw + kbase + kq16;
-#ifdef CR_KO_W8CONTIG   // knock-out (wrong results, cost structure only): the e4m3 weights read as contiguous KiB blocks, what a decode layout of the fp8 copies would give
-        constexpr int W8STEP = 1024;
+        // decode layout of the e4m3 copy (p.wsw, gemm_decode.hip: decode_swizzle8_kernel): a load instruction is one contiguous KiB instead of 16 rows x 64 bytes
+        // (64 rows: a step 9.76 -> 8.83 ms when this was a knock-out in round 4, 16 rows 4.53 -> 3.91)
+        const int W8STEP = p.wsw ? 1024 : 64;
+        if (p.wsw) {
 #pragma unroll
-        for (int r = 0; r < RT; r++) w8p[r] = (const unsigned char*)p.W + ((int64_t)min(n0 / 16 + r, (p.N + 15) / 16 - 1) * (p.K / 64) + kbase / 64) * 1024 + lane * 16;
-#else
-        constexpr int W8STEP = 64;
-#endif
+            for (int r = 0; r < RT; r++) w8p[r] = (const unsigned char*)p.W + ((int64_t)min(n0 / 16 + r, (p.N + 15) / 16 - 1) * (p.K / 64) + kbase / 64) * 1024 + lane * 16;
+        }
         const bf16* x8p[MT];
 #pragma unroll
         for (int t = 0; t < MT; t++) x8p[t] = p.A + (int64_t)min(t * 16 + (lane & 15), p.M - 1) * p.lda + kbase + kq16;

@@ -302,15 +302,17 @@ int rms(const bf16* in, int64_t ld_in, bf16* out, const bf16* w, int64_t rows, f
 
 // the same GEMM on the e4m3 copy of a weight (decode only): C = (A . W8^T) * wscale
 int gemm8(cr_ctx* c, int epi, const bf16* A, int64_t lda, const DevTensor* w8, const DevTensor* ws, void* C, int64_t ldc, const bf16* res,
-          int64_t ldr, int M, int N, int K, hipStream_t st) {
+          int64_t ldr, int M, int N, int K, hipStream_t st, const DevTensor* dl = nullptr) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = (const bf16*)w8->ptr; p.ldw = K; p.C = C; p.ldc = ldc; p.res = res; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
     p.w8 = 1; p.wscale = (const float*)ws->ptr;
+    if (dl && M <= 64) { p.W = (const bf16*)dl->ptr; p.wsw = 1; }       // the e4m3 copy in its decode layout (cr_enable_fp8_decode): a contiguous KiB per load instruction
     return ctx_gemm(c, epi, p, st);
 }
 
 struct LayerW { const bf16 *an, *fn, *wqkv, *wo, *w13, *w2; const DevTensor *d_qkv, *d_o, *d_13, *d_2;      // d_*: decode-layout copies (llm_finalize), may be null
-                const DevTensor *q_qkv, *s_qkv, *q_o, *s_o, *q_13, *s_13, *q_2, *s_2; };
+                const DevTensor *q_qkv, *s_qkv, *q_o, *s_o, *q_13, *s_13, *q_2, *s_2;
+                const DevTensor *l_qkv, *l_o, *l_13, *l_2; };      // l_*: the e4m3 copies in their decode layout (cr_enable_fp8_decode), may be null
 
 const DevTensor* opt(cr_ctx* c, const std::string& name) {
     auto it = c->w.find(name);
@@ -328,6 +330,8 @@ int layer_weights(cr_ctx* c, int l, LayerW& w) {
     w.q_o = opt(c, "fp8." + p + "attention.wo.weight"); w.s_o = opt(c, "fp8s." + p + "attention.wo.weight");
     w.q_13 = opt(c, "fp8.derived.w13." + std::to_string(l)); w.s_13 = opt(c, "fp8s.derived.w13." + std::to_string(l));
     w.q_2 = opt(c, "fp8." + p + "feed_forward.w2.weight"); w.s_2 = opt(c, "fp8s." + p + "feed_forward.w2.weight");
+    w.l_qkv = opt(c, "fp8dl." + p + "attention.wqkv.weight"); w.l_o = opt(c, "fp8dl." + p + "attention.wo.weight");
+    w.l_13 = opt(c, "fp8dl.derived.w13." + std::to_string(l)); w.l_2 = opt(c, "fp8dl." + p + "feed_forward.w2.weight");
     return (w.an && w.fn && w.wqkv && w.wo && w.w13 && w.w2) ? CR_OK : CR_ERR_STATE;
 }
 
@@ -429,9 +433,9 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
         if (!sliced || l == 0) CR_TRY(rms(x, D, h, w.an, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         const bool f8 = decode && M <= 64 && c->fp8_decode && w.q_qkv && w.s_qkv && w.q_o && w.s_o && w.q_13 && w.s_13 && w.q_2 && w.s_2;
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_STORE, h, hs, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, M, QKV, D, st));
-        else if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st)
+        else if (sliced) CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, h, D, w.q_qkv, w.s_qkv, pbuf, QKV, nullptr, 0, M, QKV, D, st, w.l_qkv)
                                : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st, false, w.d_qkv, 2));
-        else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st)
+        else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st, w.l_qkv)
                         : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st, !decode));
         hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
                            decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens,
@@ -472,7 +476,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             if (launch_flash_attn_split(ap, HD, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
         }
         if (sliced) {
-            CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, ao, D, w.q_o, w.s_o, pbuf, D, nullptr, 0, M, D, D, st)
+            CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, ao, D, w.q_o, w.s_o, pbuf, D, nullptr, 0, M, D, D, st, w.l_o)
                       : gemm(c, EPI_PARTIAL, ao, D, w.wo, D, pbuf, D, nullptr, 0, M, D, D, st, false, w.d_o));
             CR_TRY(launch_add_rmsnorm(x, pbuf, s_o, M, w.fn, h, c->d.rms_eps, st));
         } else {
@@ -480,16 +484,16 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                 hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, ao, (int64_t)D, D, a8, hs);
                 CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_o, w.s_o, x, D, nullptr, M, D, D, st, x, D));
             } else {
-                CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st)
+                CR_TRY(f8 ? gemm8(c, EPI_RES, ao, D, w.q_o, w.s_o, x, D, x, D, M, D, D, st, w.l_o)
                           : gemm(c, EPI_RES, ao, D, w.wo, D, x, D, x, D, M, D, D, st, !decode));
             }
             CR_TRY(rms(x, D, h, w.fn, M, c->d.rms_eps, st, m8 ? hs : nullptr));
         }
         if (m8) CR_TRY(ctx_gemm_f8(c, EPI_SWIGLU, h, hs, w.q_13, w.s_13, act, ff, nullptr, M, 2 * ff, D, st));
-        else CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st)
+        else CR_TRY(f8 ? gemm8(c, EPI_SWIGLU, h, D, w.q_13, w.s_13, act, ff, nullptr, 0, M, 2 * ff, D, st, w.l_13)
                        : gemm(c, EPI_SWIGLU, h, D, w.w13, D, act, ff, nullptr, 0, M, 2 * ff, D, st, !decode, decode ? w.d_13 : nullptr));
         if (sliced) {
-            CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, act, ff, w.q_2, w.s_2, pbuf, D, nullptr, 0, M, D, ff, st)
+            CR_TRY(f8 ? gemm8(c, EPI_PARTIAL, act, ff, w.q_2, w.s_2, pbuf, D, nullptr, 0, M, D, ff, st, w.l_2)
                       : gemm(c, EPI_PARTIAL, act, ff, w.w2, ff, pbuf, D, nullptr, 0, M, D, ff, st, false, w.d_2));
             const bf16* next_norm = nullptr;             // the last layer's sum only lands in x: the caller norms what it needs
             if (l + 1 < c->d.llm_layers) {
@@ -502,7 +506,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, act, (int64_t)ff, ff, a8, hs);
             CR_TRY(ctx_gemm_f8(c, EPI_RES, a8, hs, w.q_2, w.s_2, x, D, nullptr, M, D, ff, st, x, D));
         } else {
-            CR_TRY(f8 ? gemm8(c, EPI_RES, act, ff, w.q_2, w.s_2, x, D, x, D, M, D, ff, st)
+            CR_TRY(f8 ? gemm8(c, EPI_RES, act, ff, w.q_2, w.s_2, x, D, x, D, M, D, ff, st, w.l_2)
                       : gemm(c, EPI_RES, act, ff, w.w2, ff, x, D, x, D, M, D, ff, st, !decode));
         }
         CR_TRY(probe(l + 1));
@@ -689,6 +693,27 @@ int cr_enable_fp8_decode(cr_ctx* c, int enable, void* stream) {
     }
     names.push_back("language_model.output.weight");
     for (const std::string& nm : names) CR_TRY(build_fp8_copy(c, nm, 512, st));
+    // ... and each of them once more in the decode layout (gemm_decode.hip: decode_swizzle8_kernel; + 7.7 GB on InternLM2.5-7B): without it the e4m3-weight
+    // decode LOST to the bf16 decode on ITS decode layout (round 4: 9.76 against 9.23 ms per 64-row step).  All or nothing; CR_DECODE_LAYOUT=0: none.
+    {
+        const char* e = getenv("CR_DECODE_LAYOUT");
+        bool ok = !(e && atoi(e) == 0);
+        for (size_t i = 0; ok && i < names.size(); i++) {
+            const std::string& nm = names[i];
+            if (c->w.count("fp8dl." + nm)) continue;
+            const DevTensor* q8 = WT(c, "fp8." + nm);
+            if (!q8 || q8->shape.size() != 2) { ok = false; break; }
+            DevTensor t;
+            t.dtype = CR_U8; t.shape = {(q8->shape[0] + 15) / 16 * 16, q8->shape[1]}; t.bytes = decode_swizzled8_bytes((int)q8->shape[0], (int)q8->shape[1]);
+            if (hipMalloc(&t.ptr, t.bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            if (decode_swizzle_weight8((const unsigned char*)q8->ptr, q8->shape[1], (int)q8->shape[0], (int)q8->shape[1], (unsigned char*)t.ptr, st) != CR_OK) { hipFree(t.ptr); ok = false; break; }
+            c->w["fp8dl." + nm] = t;
+        }
+        if (!ok)
+            for (auto it = c->w.begin(); it != c->w.end();) {
+                if (it->first.rfind("fp8dl.", 0) == 0) { hipFree(it->second.ptr); it = c->w.erase(it); } else ++it;
+            }
+    }
     CR_HIP(hipGetLastError());
     CR_HIP(hipStreamSynchronize(st));
     c->fp8_decode = true;
@@ -905,7 +930,7 @@ int cr_llm_decode(cr_ctx* c, cr_kv* kv, const int32_t* seqs, int n, const int64_
             CR_TRY(launch_decode_gemm(DEC_HEAD, dh, st));
         } else {
         CR_TRY(rms(x, D, hl, nw, n, c->d.rms_eps, st));
-        if (c->fp8_decode && n <= 64 && q_out && s_out) CR_TRY(gemm8(c, EPI_F32, hl, D, q_out, s_out, lg, V, nullptr, 0, n, V, D, st));
+        if (c->fp8_decode && n <= 64 && q_out && s_out) CR_TRY(gemm8(c, EPI_F32, hl, D, q_out, s_out, lg, V, nullptr, 0, n, V, D, st, opt(c, "fp8dl.language_model.output.weight")));
         else CR_TRY(gemm(c, EPI_F32, hl, D, ow, D, lg, V, nullptr, 0, n, V, D, st, false, opt(c, "declayout.language_model.output.weight")));
         }
         if (logits) CR_HIP(hipMemcpyAsync(logits, lg, (size_t)n * V * 4, hipMemcpyDeviceToDevice, st));

@@ -302,16 +302,28 @@ def op_quantize_fp8(Wt):
     return q, sc
 
 
-def op_gemm_fp8(epi, A, q, sc, res=None, out_dtype=torch.bfloat16):
-    """cr_op_gemm with e4m3 weights `q` [N, K] and row scales `sc` (decode kernel, M <= 64)."""
+def op_decode_swizzle8(q):
+    """cr_op_decode_swizzle(which = 8): the decode layout of an e4m3 [N, K] weight copy (1 KiB per 16-row tile and 64-deep k-step)."""
+    N, K = q.shape
+    out = torch.empty(((N + 15) // 16) * 16 * K, dtype=torch.uint8, device=q.device)
+    B.check(B.lib.cr_op_decode_swizzle(8, _p(q), q.stride(0), N, K, _p(out), _stream()), 'cr_op_decode_swizzle(e4m3)')
+    return out
+
+
+def op_gemm_fp8(epi, A, q, sc, res=None, out_dtype=torch.bfloat16, decode_layout=None):
+    """cr_op_gemm with e4m3 weights `q` [N, K] and row scales `sc` (decode kernel, M <= 64); decode_layout = op_decode_swizzle8(q): the kernel streams that copy."""
     M, K = A.shape
     N = q.shape[0]
+    hi = 0
+    if decode_layout is not None:
+        hi = 1 << 18
+        q = decode_layout.view(-1, K)
     ncols = N // 2 if epi == 4 else N
     mrows = M
     if epi == 7:
         mrows, out_dtype = 8 * M, torch.float32
     Cc = torch.zeros(mrows, ncols, device=A.device, dtype=out_dtype)
-    B.check(B.lib.cr_op_gemm(epi | (1 << 16), _p(A), A.stride(0), _p(q), q.stride(0), _p(Cc), Cc.stride(0), _p(None), _p(sc),
+    B.check(B.lib.cr_op_gemm(epi | (1 << 16) | hi, _p(A), A.stride(0), _p(q), q.stride(0), _p(Cc), Cc.stride(0), _p(None), _p(sc),
                              _p(res), res.stride(0) if res is not None else 0, M, N, K, 0, _stream()), 'cr_op_gemm(fp8)')
     return Cc
 

@@ -57,7 +57,12 @@ def test_fp8_weight_gemm_is_exact_on_representable_data(E, M, N, K, epi):
     res = torch.randint(-3, 4, (M, N), generator=g).float().bfloat16() if epi == 3 else None
     out = E.op_gemm_fp8(epi, X.bfloat16().cuda(), q, sc, res=res.cuda() if res is not None else None,
                         out_dtype=torch.float32 if epi == 6 else torch.bfloat16)
+    # the e4m3 copy's decode layout (round 5: cr_enable_fp8_decode keeps it; one contiguous KiB per load instruction): the same values in the same
+    # registers, so the same bits -- ragged N included (5, 9000)
+    out_dl = E.op_gemm_fp8(epi, X.bfloat16().cuda(), q, sc, res=res.cuda() if res is not None else None,
+                           out_dtype=torch.float32 if epi == 6 else torch.bfloat16, decode_layout=E.op_decode_swizzle8(q))
     torch.cuda.synchronize()
+    assert torch.equal(out_dl, out)
     acc = X @ W.t()
     if epi == 7:                                               # fp32 K-slices: their sum is the product
         got = out.reshape(8, M, N).sum(dim=0).cpu()
@@ -112,6 +117,22 @@ def test_fp8_decode_against_the_bf16_path():
     print(f'fp8 decode vs bf16: worst logits rel-L2 {worst:.3e}, greedy picks equal {agree}/{total}')
     assert worst <= 1.5e-1, worst
     assert agree >= total * 0.6, (agree, total)                # flat random-weight logits: most picks still agree
+    # with and without the decode layout of the e4m3 copies: the same bits (a second context built under CR_DECODE_LAYOUT=0)
+    import os
+    fp8_logits, fp8_ids = run(True)
+    os.environ['CR_DECODE_LAYOUT'] = '0'
+    try:
+        plain = Engine(dims, max_pos=1024)
+        plain.load_state_dict(sd); plain.load_rope(); plain.finalize()
+        plain.enable_fp8_decode(True)
+    finally:
+        del os.environ['CR_DECODE_LAYOUT']
+    kvp = plain.kv_alloc(3, 512)
+    plain.prefill_batch(kvp, [0, 1, 2], prompts)
+    for t in range(steps):
+        assert torch.equal(plain.decode(kvp, [0, 1, 2], want_logits=True).float().cpu(), fp8_logits[t]), t
+    assert [kvp.generated(i) for i in range(3)] == fp8_ids
+    kvp.free(); plain.close()
     # switching back restores the bf16 results bit for bit
     again, ids2 = run(False)
     assert ids2 == ref_ids and all(torch.equal(a, b) for a, b in zip(again, ref_logits))
