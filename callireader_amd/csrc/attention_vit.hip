@@ -42,14 +42,20 @@ __device__ __forceinline__ float rbf1(float x) {
     return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)));
 }
 
-constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB, KS = 4, DB = 2, CPR = 8, RPI = 8, IPW = 2;
+constexpr int D = 64, ROWB = 128, TILE = 64 * ROWB, KS = 4, DB = 2, CPR = 8, RPI = 8;
 __device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
 // One 128-query block of one (tile, head).  EXACT = false: the lean sweep, the block's verdict on it (flag), the output, the block's
 // share of the CLS query.  EXACT = true: the same block again in the exact rescaling form (vit_attn_exact_kernel, flagged blocks only).
-template <bool EXACT>
+// NW = waves per workgroup (of 128 queries): 4 waves of 32 queries (round 2..4), or -- round 5, CR_VIT_ATTN_NW=2 -- 2 waves of 64: a wave then holds TWO 32-query
+// sub-blocks and every K / V fragment it reads from LDS feeds two MFMAs instead of one (the knock-outs of profiles/round5/06_* put the matrix side of this
+// kernel -- MFMAs + fragment reads + fills, no softmax -- at 0.281 ms of the launch's 0.346 and the vector side alone at 0.246: the matrix side is the longer
+// one, and it is twice its pure MFMA time; what it waits for is LDS).  The same arithmetic per query either way: the same bits.
+template <bool EXACT, int NW = 4>
 __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb, const int head, const int batch, const int gx) {
+    constexpr int QB = 4 / NW;                               // 32-query sub-blocks per wave
+    constexpr int IPW = 8 / NW;                              // 8-row staging pieces (K and V each) per wave and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -61,7 +67,9 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     const bf16* Vc = p.V + (int64_t)batch * p.v_bs + (int64_t)head * p.v_hs;
     const bf16* Kb = Kc + p.k_rs;                                                     // patch keys, zero-based
     const bf16* Vb = Vc + p.v_rs;
-    const int qrow = 1 + qb * 128 + wave * 32 + l31;
+    int qrow[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) qrow[j] = 1 + qb * 128 + (wave * QB + j) * 32 + l31;
 
     // ---- Q fragment (B operand of K.Q^T): lane (query l31, half hh) holds Q[q][16ks + 8hh .. +7], times 2^-3 in bf16 ----
     auto load_q = [&](int row, bf16x8* dst) {
@@ -86,8 +94,9 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         }
         return part + __shfl_xor(part, 32, 64);
     };
-    bf16x8 qf[KS];
-    load_q(qrow, qf);
+    bf16x8 qf[QB][KS];
+#pragma unroll
+    for (int j = 0; j < QB; j++) load_q(qrow[j], qf[j]);
 
     // ---- staging: one 32-bit per-lane byte offset for K and one for V (row r = lane / 8 of an 8-row piece, swizzled 16-byte chunk);
     // the piece, the tile and the (batch, head) go into the instruction's scalar base.  LDS-DMA is issued from inline asm (M0 = LDS
@@ -138,9 +147,11 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             vsrc[ii] += v_step;
         }
     };
-    f32x16 oacc[DB];
-    float m_run, l_run;
-    f32x4 lsum = {0.f, 0.f, 0.f, 0.f};                      // lean sweep: row sums (softmax32)
+    f32x16 oacc[QB][DB];
+    float m_run[QB], l_run[QB];
+    f32x4 lsum[QB];                                         // lean sweep: row sums (softmax32)
+#pragma unroll
+    for (int j = 0; j < QB; j++) lsum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 sel;
     {
         const int sr_ = lane & 15, sj_ = lane >> 4;
@@ -174,6 +185,17 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         }
         return s;
     };
+    // the same for BOTH of a wave's query sub-blocks off ONE read of every K fragment (NW = 2)
+    auto qk32x2 = [&](const char* kbuf, int kb, const bf16x8* qa, const bf16x8* qb_, f32x16& sa, f32x16& sb) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) { sa[e] = 0.f; sb[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const bf16x8 kf = *(const bf16x8*)(kbuf + kb * 32 * ROWB + k_lane_off + (((2 * ks + hh) ^ k_sw) * 16));
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qa[ks], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb_[ks], sb, 0, 0, 0);
+        }
+    };
     // O^T += V^T[32 keys] . P^T: 4 MFMAs; pk = the block's 8 packed bf16 pairs
     auto pv32 = [&](const char* vbuf, int kb, const unsigned* pk, f32x16* o) {
 #ifdef CR_KO_VIT_MFMA
@@ -197,13 +219,31 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         }
     };
 
+    auto pv32x2 = [&](const char* vbuf, int kb, const unsigned* pka, const unsigned* pkb, f32x16* oa, f32x16* ob) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const u32x4_t pwa = {pka[4 * s], pka[4 * s + 1], pka[4 * s + 2], pka[4 * s + 3]}, pwb = {pkb[4 * s], pkb[4 * s + 1], pkb[4 * s + 2], pkb[4 * s + 3]};
+            const bf16x8 pfa = __builtin_bit_cast(bf16x8, pwa), pfb = __builtin_bit_cast(bf16x8, pwb);
+#pragma unroll
+            for (int db = 0; db < DB; db++) {
+                const int chunk = ((db * 4) ^ v_sw) | v_clow;
+                const char* vp = vbuf + (kb * 32 + 16 * s) * ROWB + v_lane_off + chunk * 16;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)CR_LDS(vp + 8 * ROWB));
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfa, oa[db], 0, 0, 0);
+                ob[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfb, ob[db], 0, 0, 0);
+            }
+        }
+    };
+
     // one 32-key block of scores -> P (packed bf16 pairs) and the row-sum update, lean form (attention.hip): the reference point
     // stays where the CLS key put it; per score one v_cvt_pk_bf16_f32 (0, s), one FMA, one v_exp_f32, half an add, half a v_cvt_pk.
     // No branch, no rescale inside the sweep: P is bf16 (fp32's exponent range) and O, l are fp32, so scores up to ~88 above the
     // reference point are still exact relative arithmetic; what lies beyond shows as a non-finite or > 2^100 row sum at the END of the
     // sweep, and the whole block then repeats the sweep in the exact rescaling form (exact_sweep below).  A per-tile check with an
     // in-loop fallback made hipcc copy the 32 accumulators twice per tile (40 v_mov_b64).
-    auto softmax32 = [&](const f32x16& sc, unsigned* pk, float m2f) {
+    auto softmax32 = [&](const f32x16& sc, unsigned* pk, float m2f, f32x4& lsum) {
 #ifdef CR_KO_VIT_SOFTMAX   // knock-out (wrong results, cost structure only): no rounding, FMA, exponential or packing -- what the matrix pipe, the fragment reads and the fills take alone
 #pragma unroll
         for (int j = 0; j < 8; j++) pk[j] = __float_as_uint(sc[2 * j]) ^ __float_as_uint(sc[2 * j + 1]);
@@ -234,7 +274,7 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
 #endif
     };
     // the same block in the exact form: running maximum, rescale of O and l when it grows (only exact_sweep uses it)
-    auto softmax32_exact = [&](const f32x16& sc, unsigned* pk) {
+    auto softmax32_exact = [&](const f32x16& sc, unsigned* pk, float& m_run, float& l_run, f32x16* oacc) {
         float mraw = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; e++) mraw = fmaxf(mraw, sc[e]);
@@ -259,16 +299,19 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             for (int e = 0; e < 16; e++) oacc[db][e] *= alpha;
     };
     auto init_state = [&]() {                               // the CLS key as the initial softmax state
-        m_run = rbf1(dot_cls_key(qf));                      // its score, rounded to bf16 like every score: P = exp(0) = 1
-        l_run = hh == 0 ? 1.0f : 0.0f;                      // row sums are kept per half-wave and added at the end
 #pragma unroll
-        for (int db = 0; db < DB; db++)
+        for (int j = 0; j < QB; j++) {
+            m_run[j] = rbf1(dot_cls_key(qf[j]));            // its score, rounded to bf16 like every score: P = exp(0) = 1
+            l_run[j] = hh == 0 ? 1.0f : 0.0f;               // row sums are kept per half-wave and added at the end
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const bf16x4 v0 = *(const bf16x4*)(Vc + 32 * db + 8 * g4 + 4 * hh);
+            for (int db = 0; db < DB; db++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) oacc[db][4 * g4 + e] = bf2f(v0[e]);
-            }
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const bf16x4 v0 = *(const bf16x4*)(Vc + 32 * db + 8 * g4 + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) oacc[j][db][4 * g4 + e] = bf2f(v0[e]);
+                }
+        }
     };
     // one sweep over the NT key tiles in the rotated order; ends with tiles 2qb / 2qb + 1 in LDS buffers 0 / 1
     auto sweep = [&](auto exact) {
@@ -277,7 +320,9 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         seek(kt);
         stage(0);
         init_state();
-        const float m2f = m_run * LOG2E;
+        float m2f[QB];
+#pragma unroll
+        for (int j = 0; j < QB; j++) m2f[j] = m_run[j] * LOG2E;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // two tiles per trip: the buffer a tile sits in is a compile-time constant, so its LDS offsets are instruction immediates
@@ -297,14 +342,30 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             // eight K.Q^T MFMAs, which fit into the issue slots the vector work leaves.  Same run, 255 tiles: no priorities 1.399 ms,
             // this 1.359, the reverse (K.Q^T high) 1.385, one static priority per workgroup parity 1.382.
             if (!decltype(exact)::value) __builtin_amdgcn_s_setprio(0);
-            const f32x16 s0 = qk32(kbuf, 0, qf);
-            const f32x16 s1 = qk32(kbuf, 1, qf);
-            if (!decltype(exact)::value) __builtin_amdgcn_s_setprio(1);
-            unsigned pk0[8], pk1[8];
-            if (decltype(exact)::value) softmax32_exact(s0, pk0); else softmax32(s0, pk0, m2f);
-            pv32(vbuf, 0, pk0, oacc);
-            if (decltype(exact)::value) softmax32_exact(s1, pk1); else softmax32(s1, pk1, m2f);
-            pv32(vbuf, 1, pk1, oacc);
+            if constexpr (QB == 1) {
+                const f32x16 s0 = qk32(kbuf, 0, qf[0]);
+                const f32x16 s1 = qk32(kbuf, 1, qf[0]);
+                if (!decltype(exact)::value) __builtin_amdgcn_s_setprio(1);
+                unsigned pk0[8], pk1[8];
+                if (decltype(exact)::value) softmax32_exact(s0, pk0, m_run[0], l_run[0], oacc[0]); else softmax32(s0, pk0, m2f[0], lsum[0]);
+                pv32(vbuf, 0, pk0, oacc[0]);
+                if (decltype(exact)::value) softmax32_exact(s1, pk1, m_run[0], l_run[0], oacc[0]); else softmax32(s1, pk1, m2f[0], lsum[0]);
+                pv32(vbuf, 1, pk1, oacc[0]);
+            } else {
+                // two sub-blocks A, B per wave: every K / V fragment read feeds both; block by block, as above
+                // (K.Q^T of both 32-key blocks first, as in the four-wave form: block 0's P.V MFMAs run under block 1's softmax)
+                f32x16 sa[2], sb[2];
+                unsigned pka[8], pkb[8];
+                qk32x2(kbuf, 0, qf[0], qf[QB - 1], sa[0], sb[0]);
+                qk32x2(kbuf, 1, qf[0], qf[QB - 1], sa[1], sb[1]);
+                if (!decltype(exact)::value) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+                    if (decltype(exact)::value) { softmax32_exact(sa[kb], pka, m_run[0], l_run[0], oacc[0]); softmax32_exact(sb[kb], pkb, m_run[QB - 1], l_run[QB - 1], oacc[QB - 1]); }
+                    else { softmax32(sa[kb], pka, m2f[0], lsum[0]); softmax32(sb[kb], pkb, m2f[QB - 1], lsum[QB - 1]); }
+                    pv32x2(vbuf, kb, pka, pkb, oacc[0], oacc[QB - 1]);
+                }
+            }
             // the next tile's fill has had this whole tile to land; every wave's pieces must be in before any wave reads them.
             // lgkmcnt(0) as well: hipcc waits for the tile's LAST V fragments behind the barrier (in front of the MFMA that takes them),
             // and behind the barrier another wave's fill of this very buffer may already be landing -- from the vector L1 when a
@@ -323,45 +384,52 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     // vote -- the kernel took 168 registers for code that all but never runs: 3 waves per SIMD; alone the lean form fits 128 and
     // four: 1.478 -> 1.412 ms per 255-tile launch in one process.)
     int* const flags = (int*)(p.part_o + (size_t)p.B * p.H * (4 * gx + 1) * D);
-    float l_tot;
+    float l_tot[QB];
     if constexpr (!EXACT) {
         sweep(std::false_type{});
         __builtin_amdgcn_s_setprio(0);
-        {   // query q's sum: lane q & 15, register q >> 4; + 1 for the CLS key (exp(0))
-            const float v0 = __shfl(lsum[0], l31 & 15, 64), v1 = __shfl(lsum[1], l31 & 15, 64);
-            l_tot = 1.0f + (l31 < 16 ? v0 : v1);
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < QB; j++) {   // query q's sum: lane q & 15, register q >> 4; + 1 for the CLS key (exp(0))
+            const float v0 = __shfl(lsum[j][0], l31 & 15, 64), v1 = __shfl(lsum[j][1], l31 & 15, 64);
+            l_tot[j] = 1.0f + (l31 < 16 ? v0 : v1);
+            mine |= !(l_tot[j] < 1.2676506002282294e30f);
         }
-        const int bad = __syncthreads_or(!(l_tot < 1.2676506002282294e30f));
+        const int bad = __syncthreads_or(mine);
         if (tid == 0) flags[((int64_t)batch * p.H + head) * gx + qb] = bad;
     } else {
         sweep(std::true_type{});
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+#pragma unroll
+        for (int j = 0; j < QB; j++) l_tot[j] = l_run[j] + __shfl_xor(l_run[j], 32, 64);
     }
 
     // ---- patch queries: normalise and store; lane (query, half) owns d = 32db + 8g4 + 4hh + 0..3 ----
-    {
-        const float inv = 1.0f / l_tot;
-        bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        const float inv = 1.0f / l_tot[j];
+        bf16* op = p.O + (int64_t)batch * p.o_bs + (int64_t)qrow[j] * p.o_rs + (int64_t)head * p.o_hs + 4 * hh;
 #pragma unroll
         for (int db = 0; db < DB; db++)
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; e++) o[e] = f2bf(oacc[db][4 * g4 + e] * inv);
+                for (int e = 0; e < 4; e++) o[e] = f2bf(oacc[j][db][4 * g4 + e] * inv);
                 *(bf16x4*)(op + 32 * db + 8 * g4) = o;
             }
     }
 
     if constexpr (EXACT) return;
     // ---- the CLS query: this wave's 32 keys of the block's last two tiles (still in LDS: tile 2qb in buffer 0, 2qb + 1 in buffer 1)
-    load_q(0, qf);                                          // every lane column holds the same query
+    load_q(0, qf[0]);                                       // every lane column holds the same query
     const int nsplit = 4 * gx + 1;
     const int64_t prow = ((int64_t)batch * p.H + head) * nsplit;
-    {
-        const char* kbuf = smem + (wave >> 1) * (2 * TILE);
-        const int kb = wave & 1;
-        const f32x16 s = qk32(kbuf, kb, qf);
+#pragma unroll
+    for (int hf_ = 0; hf_ < QB; hf_++) {                    // four 32-key halves per block, 4 / NW of them per wave
+        const int hf = wave * QB + hf_;
+        const char* kbuf = smem + (hf >> 1) * (2 * TILE);
+        const int kb = hf & 1;
+        const f32x16 s = qk32(kbuf, kb, qf[0]);
         float mraw = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; e++) mraw = fmaxf(mraw, s[e]);
@@ -385,7 +453,7 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
             for (int e = 0; e < 16; e++) oc[db][e] = 0.f;
         pv32(kbuf + TILE, kb, pk, oc);
         if (l31 == 0) {
-            const int64_t row = prow + qb * 4 + wave;
+            const int64_t row = prow + qb * 4 + hf;
             if (hh == 0) { p.part_ml[row * 2] = m; p.part_ml[row * 2 + 1] = l; }
             float* po = p.part_o + row * D + 4 * hh;
 #pragma unroll
@@ -396,7 +464,7 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
         }
     }
     if (qb == 0 && wave == 0) {                             // ... and the CLS key itself: a one-key partial, P = 1
-        const float s0 = rbf1(dot_cls_key(qf));
+        const float s0 = rbf1(dot_cls_key(qf[0]));
         if (l31 == 0) {
             const int64_t row = prow + 4 * gx;
             if (hh == 0) { p.part_ml[row * 2] = s0; p.part_ml[row * 2 + 1] = 1.0f; }
@@ -412,6 +480,15 @@ __device__ __forceinline__ void vit_attn_body(const AttnParams& p, const int qb,
     }
 }
 
+// the two-wave form: 128 threads, 64 queries per wave (CR_VIT_ATTN_NW=2)
+__global__ __launch_bounds__(128, 2) void vit_attn2_kernel(const AttnParams p) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * (int)gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * (int)blockIdx.z);
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    vit_attn_body<false, 2>(p, pid % gx, (pid / gx) % gy, pid / (gx * gy), gx);
+}
 __global__ __launch_bounds__(256, 4) void vit_attn_kernel(const AttnParams p) {
     // XCD-aware order (attention.hip): the query blocks of one (tile, head) read their K/V through ONE L2
     const int gx = gridDim.x, gy = gridDim.y;
@@ -491,12 +568,16 @@ size_t vit_attn_ws_floats(int B, int H, int S) { const int nb = (S - 1) / 128; r
 
 int launch_vit_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * TILE;
-    static std::atomic<uint64_t> attr_done{0}, attr_done_x{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS) || !cr_dyn_lds_once(attr_done_x, (const void*)vit_attn_exact_kernel, LDS)) return CR_ERR_HIP;
+    static std::atomic<uint64_t> attr_done{0}, attr_done_x{0}, attr_done_2{0};
+    if (!cr_dyn_lds_once(attr_done, (const void*)vit_attn_kernel, LDS) || !cr_dyn_lds_once(attr_done_x, (const void*)vit_attn_exact_kernel, LDS) ||
+        !cr_dyn_lds_once(attr_done_2, (const void*)vit_attn2_kernel, LDS)) return CR_ERR_HIP;
+    const char* e_nw = getenv("CR_VIT_ATTN_NW");                 // read per call (a bench flips it in one process)
+    const bool two_waves = e_nw && e_nw[0] == '2';
     const int nb = (p.Sq - 1) / 128;
     AttnParams q = p;
     q.part_o = p.part_ml + (size_t)p.B * p.H * (4 * nb + 1) * 2;       // one allocation: [m, l] pairs, then the O partials
-    hipLaunchKernelGGL(vit_attn_kernel, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
+    if (two_waves) hipLaunchKernelGGL(vit_attn2_kernel, dim3(nb, p.H, p.B), dim3(128), LDS, stream, q);
+    else hipLaunchKernelGGL(vit_attn_kernel, dim3(nb, p.H, p.B), dim3(256), LDS, stream, q);
     hipLaunchKernelGGL(vit_attn_exact_kernel, dim3(p.B), dim3(256), LDS, stream, q, nb);
     if (nb == 8) hipLaunchKernelGGL(vit_cls_combine_kernel<33>, dim3(p.H, p.B), dim3(64), 0, stream, q);
     else hipLaunchKernelGGL(vit_cls_combine_any_kernel, dim3(p.H, p.B), dim3(64), 0, stream, q, 4 * nb + 1);

@@ -571,6 +571,34 @@ def test_attention_vit_launches_back_to_back_are_identical(E, monkeypatch):
         assert float((outs[0].float() - ref.float()).abs().max()) <= 2 ** -7
 
 
+def test_attention_vit_two_wave_form_gives_the_four_wave_forms_bits(E, monkeypatch):
+    """attention_vit.hip, round 5: workgroups of TWO waves with 64 queries each (CR_VIT_ATTN_NW=2: every K / V fragment read from LDS feeds two MFMAs)
+    beside the four-wave form.  Per query the arithmetic is the same instruction sequence, so the outputs must be the same bits -- ordinary data (CLS row
+    and its partial / combine path included), the spiked data that sends blocks through the exact re-sweep, and back-to-back launches as a race screen."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    Bn, S, H, D = 40, 1025, 16, 64
+    C3, C1 = 3 * H * D, H * D
+    qkv = torch.randn(Bn, S, C3, device=dev(), generator=g).bfloat16()
+    qkv[1, 5, 0:D] = 4.0; qkv[1, 0, C1:C1 + D] = -4.0; qkv[1, 400, C1:C1 + D] = 4.0       # tile 1, head 0: a flagged block (exact re-sweep)
+    strides = [S * C3, C3, D, S * C3, C3, D, S * C3, C3, D, S * C1, C1, D]
+
+    def launch(o):
+        E.op_attention(qkv, qkv[:, :, C1:], qkv[:, :, 2 * C1:], o, strides, Bn, H, S, S, D, q_prescale=0.125)
+    monkeypatch.setenv('CR_VIT_ATTN_NW', '4')
+    ref = torch.zeros(Bn, S, C1, device=dev(), dtype=torch.bfloat16)
+    launch(ref)
+    torch.cuda.synchronize()
+    monkeypatch.setenv('CR_VIT_ATTN_NW', '2')
+    for _ in range(3):
+        outs = [torch.full((Bn, S, C1), 7.0, device=dev(), dtype=torch.bfloat16) for _ in range(6)]
+        for o in outs:
+            launch(o)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, ref)
+    assert torch.isfinite(ref.float()).all()
+
+
 def test_attention_exact_identity_layout(E):
     """V = one-hot rows, uniform scores: output row = mean of V rows -> exact in bf16; catches V^T/tr-read mistakes."""
     Bn, S, H, D = 1, 64, 1, 64
