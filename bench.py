@@ -284,7 +284,7 @@ def main():
     ap.add_argument('--no-strong-share', action='store_true', help='N = 1: do not time one rank\'s share of the strong-scaling step (strong_share)')
     ap.add_argument('--share-world', type=int, default=8, help='the world size whose rank-0 share strong_share runs on this one GPU')
     ap.add_argument('--share-steps', type=int, default=2, help='timed steps of strong_share')
-    ap.add_argument('--fp8-extras', action='store_true', help='also time the batched decode on e4m3 weight copies (fp8_decode; 1.03-1.09x at 64 rows, so not in the default line)')
+    ap.add_argument('--fp8-extras', action='store_true', help='also time the batched decode on e4m3 weight copies alone (fp8_decode) and compare its first picks with the bf16 decode')
     ap.add_argument('--no-pipeline', action='store_true', help='one batch at a time (the decode of a batch does not run beside the visual stage of the next)')
     args = ap.parse_args()
     NEW_TOKENS = args.new_tokens
@@ -776,8 +776,9 @@ def main():
             step(); torch.cuda.synchronize()
             dt_step8_l1 = time.perf_counter() - t0             # level 1 alone: norm-fed linears only, decode in bf16
             eng.enable_fp8_mfma(True, level=2)
-            # (the decode stays bf16: with the decode layout of the weights a 64-row bf16 step is FASTER than the e4m3-weight one, 9.23 against 9.76 ms --
-            #  the e4m3 copies have no such layout; profiles/round4/README.md)
+            # round 5: the e4m3 copies have their decode layout and the stream kernel an e4m3 form, so the e4m3-weight decode beats the bf16 one again at every
+            # row count (64 rows 7.97 against 8.29 ms, 8 rows 3.04 against 3.93; profiles/round5/11_*, 14_*): the fp8 step decodes on it
+            eng.enable_fp8_decode(True)
             step(); torch.cuda.synchronize()
             st8 = [0.0]
             torch.cuda.synchronize(); st8[0] = time.perf_counter()
@@ -786,7 +787,8 @@ def main():
             step(); torch.cuda.synchronize()
             dt_step8 = time.perf_counter() - t0
             eng.enable_fp8_mfma(False)
-            result['fp8_mfma'] = {'what': 'one whole step (one batch at a time) with cr_enable_fp8_mfma level 2 (decode in bf16 on the decode-layout weights): ViT QKV / fc1 / fc2, mlp1[1] and all four LLM '
+            eng.enable_fp8_decode(False)
+            result['fp8_mfma'] = {'what': 'one whole step (one batch at a time) with cr_enable_fp8_mfma level 2 and cr_enable_fp8_decode (e4m3 weight copies in their decode layout): ViT QKV / fc1 / fc2, mlp1[1] and all four LLM '
                                           'prefill linears multiply e4m3 x e4m3 (per-row activation scales from the norm kernels, from fc1\'s own epilogue under a '
                                           'LayerNorm-derived bound, or from a quantiser pass; per-row weight scales; fp32 accumulation); ViT proj, attention, '
                                           'resampler, VQ, KV cache stay bf16: an option, not the headline',

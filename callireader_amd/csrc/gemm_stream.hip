@@ -26,7 +26,19 @@
 
 namespace {
 
-template <int EPI, int MT, int NW>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// 8 e4m3 bytes (two dwords) -> one bf16x8 MFMA fragment (exact: e4m3 is a subset of bf16), as in gemm_skinny.hip
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned lo, unsigned hi) {
+    const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+// W8 (round 5): the weights are e4m3 bytes with one fp32 scale per row (cr_enable_fp8_decode), walked in 64-deep steps of 16 bytes per lane exactly as
+// gemm_skinny.hip's W8 instances walk them -- fragment h (h = 0, 1) of a step pairs the weights' bytes 8h .. 8h + 7 with the X chunk at k + 8h, the quarters of K
+// restart the chain, the row scale multiplies the finished fp32 sum -- so a row's bits do not depend on which of the two kernels its batch takes.
+template <int EPI, int MT, int NW, bool W8 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p, const int ks_len, const int fold) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSC = 16;                          // k-steps of 32 per chunk: 512-deep chunks (256-deep ones, a round trip per 256 k: w1|w3 at 64 rows 59.1 us against 56.6)
@@ -43,6 +55,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     const int wstep = p.wsw ? 512 : 32;
     const bf16* wp = p.wsw ? p.W + ((int64_t)min(n0 / 16, (p.N + 15) / 16 - 1) * (p.K / 32) + k0 / 32) * 512 + lane * 8
                            : p.W + (int64_t)min(n0 + (lane & 15), p.N - 1) * p.ldw + k0 + (lane >> 4) * 8;
+    // e4m3: 64-deep steps of 16 bytes per lane; decode layout = 1 KiB per (tile, 64-deep step), a chunk = 8 KiB
+    const int w8step = p.wsw ? 1024 : 64;
+    const unsigned char* wp8 = p.wsw ? (const unsigned char*)p.W + ((int64_t)min(n0 / 16, (p.N + 15) / 16 - 1) * (p.K / 64) + k0 / 64) * 1024 + lane * 16
+                                     : (const unsigned char*)p.W + (int64_t)min(n0 + (lane & 15), p.N - 1) * p.ldw + k0 + (lane >> 4) * 16;
     // X staging: sub-tile s = (row tile s >> 3, k-step s & 7); wave w brings s = w, w + NW, ...; lane -> row lane >> 2 of the
     // sub-tile, 16-byte chunk (lane & 3) ^ 2 (row >> 3) (the image gemm256.hip reads without bank conflicts)
     const int srow = lane >> 2, schunk = (lane & 3) ^ ((srow >> 3) << 1);
@@ -59,15 +75,41 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wa[KSC], wb[KSC];
+    // (a lane's 16 weight bytes per step are a bf16x8 in the bf16 form and sixteen e4m3 in the W8 form: the same register type holds either)
+    constexpr int WR = W8 ? KSC / 2 : KSC;                   // 16-byte weight registers per chunk
+    bf16x8 wa[WR], wb[WR];
     auto loadw = [&](bf16x8* w, int c) {
+        if (W8) {
 #pragma unroll
-        for (int ks = 0; ks < KSC; ks++) w[ks] = __builtin_nontemporal_load((const bf16x8*)(wp + (c * KSC + ks) * wstep));
+            for (int s8 = 0; s8 < WR; s8++) w[s8] = __builtin_nontemporal_load((const bf16x8*)(wp8 + (int64_t)(c * WR + s8) * w8step));
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KSC; ks++) w[ks] = __builtin_nontemporal_load((const bf16x8*)(wp + (c * KSC + ks) * wstep));
+        }
     };
     f32x4 tot[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // W8: lane (row lrow, quarter g = lane >> 4) of the 64-deep step s8 holds k = 64 s8 + 16 g + 0..15: X chunks 2 (g & 1) and 2 (g & 1) + 1 of the 32-deep
+    // sub-tile 2 s8 + (g >> 1)
+    const int g4 = lane >> 4;
+    const int x8_off0 = (g4 >> 1) * 1024 + lrow * 64 + (((2 * (g4 & 1)) ^ ((lrow >> 3) << 1)) * 16);
+    const int x8_off1 = (g4 >> 1) * 1024 + lrow * 64 + (((2 * (g4 & 1) + 1) ^ ((lrow >> 3) << 1)) * 16);
     auto compute = [&](int buf, const bf16x8* w) {
+        if (W8) {
+#pragma unroll
+            for (int s8 = 0; s8 < WR; s8++) {
+                const u32x4_t wq = __builtin_bit_cast(u32x4_t, w[s8]);
+                const bf16x8 w0 = fp8x8_to_bf16(wq[0], wq[1]), w1 = fp8x8_to_bf16(wq[2], wq[3]);
+#pragma unroll
+                for (int t = 0; t < MT; t++) {
+                    const char* xb = smem + buf * CH + (t * KSC + 2 * s8) * 1024;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, *(const bf16x8*)(xb + x8_off0), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, *(const bf16x8*)(xb + x8_off1), acc[t], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KSC; ks++)
 #pragma unroll
@@ -105,6 +147,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     }
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = tot[t];
+    if (W8) {                                                 // the row's scale, once, on the finished fp32 sum (gemm_skinny.hip: `s *= p.wscale[n]`)
+        float sc[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) sc[e] = p.wscale[min(n0 + (lane >> 4) * 4 + e, p.N - 1)];
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[t][e] *= sc[e];
+    }
 
     // ---- epilogue: lane holds n = n0 + 4 (lane >> 4) + 0..3 of row m = 16 t + (lane & 15) ----
     const int g = lane >> 4, gn = n0 + g * 4;
@@ -142,14 +193,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_stream_kernel(const GemmParams p
     }
 }
 
-template <int EPI, int MT, int NW>
-int launch_nw(const GemmParams& p, hipStream_t stream, int splits) {
+template <int EPI, int MT, int NW, bool W8>
+int launch_nw8(const GemmParams& p, hipStream_t stream, int splits) {
     constexpr int LDS = 2 * MT * 16 * 1024;
     static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_stream_kernel<EPI, MT, NW>, LDS)) return CR_ERR_HIP;
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_stream_kernel<EPI, MT, NW, W8>, LDS)) return CR_ERR_HIP;
     const dim3 grid((p.N + 16 * NW - 1) / (16 * NW), splits);
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, NW>), grid, dim3(NW * 64), LDS, stream, p, p.K / splits, p.K / splits / 2048);      // chunks per quarter of K
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, NW, W8>), grid, dim3(NW * 64), LDS, stream, p, p.K / splits, p.K / splits / 2048);      // chunks per quarter of K
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
+}
+
+template <int EPI, int MT, int NW>
+int launch_nw(const GemmParams& p, hipStream_t stream, int splits) {
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_F32) {      // the e4m3 form exists for what decode streams through this kernel: w1|w3 and the LM head
+        if (p.w8) return launch_nw8<EPI, MT, NW, true>(p, stream, splits);
+    }
+    if (p.w8) return CR_ERR_ARG;
+    return launch_nw8<EPI, MT, NW, false>(p, stream, splits);
 }
 
 template <int EPI, int MT>
@@ -200,7 +260,8 @@ bool gemm_stream_supported(int epi, const GemmParams& p, int splits) {
     // exactly the launches gemm_skinny.hip would run with FOUR waves over K and whose quarters are whole 256-deep chunks
     // (9..16 rows too since the weights have their decode layout: w1|w3 at 16 rows 48 -> 41 us; up to 8 rows gemm_decode.hip's kernels run)
     static const int min_rows = [] { const char* e = getenv("CR_STREAM_MIN"); return e ? atoi(e) : 8; }();      // tuning aid
-    if (p.w8 || p.a8 || p.M <= min_rows || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
+    if (p.a8 || p.M <= min_rows || p.M > 64 || splits != 1 || p.N <= 8192 || p.K % 2048 != 0 || p.wsw > 1) return false;
+    if (p.w8 && ((epi != EPI_SWIGLU && epi != EPI_F32) || !p.wscale || (!p.wsw && (p.ldw & 15)) || p.bias)) return false;      // e4m3 weights: the two shapes decode streams here
     if ((p.lda & 7) || (!p.wsw && (p.ldw & 7)) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     if (epi == EPI_STORE || epi == EPI_F32) return true;
     if (epi == EPI_RES) return p.res != nullptr;

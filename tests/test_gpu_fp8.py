@@ -46,7 +46,8 @@ def test_row_quantiser_equals_torch_e4m3(E):
     assert int(q[6, 3]) == 0x7E                                # +448, the largest finite e4m3
 
 
-@pytest.mark.parametrize('M,N,K,epi', [(1, 4096, 4096, 0), (33, 6144, 4096, 7), (64, 4096, 14336, 7), (17, 1024, 512, 3), (40, 2048, 1024, 4), (5, 9000, 4096, 6)])
+@pytest.mark.parametrize('M,N,K,epi', [(1, 4096, 4096, 0), (33, 6144, 4096, 7), (64, 4096, 14336, 7), (17, 1024, 512, 3), (40, 2048, 1024, 4), (5, 9000, 4096, 6),
+                                       (33, 16409, 2048, 6), (64, 28672, 4096, 4), (9, 9008, 4096, 4)])      # the last three: gemm_stream.hip's e4m3 form (9..64 rows, N > 8192)
 def test_fp8_weight_gemm_is_exact_on_representable_data(E, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N)
     W = torch.randint(-7, 8, (N, K), generator=g).float()
@@ -63,6 +64,11 @@ def test_fp8_weight_gemm_is_exact_on_representable_data(E, M, N, K, epi):
                            out_dtype=torch.float32 if epi == 6 else torch.bfloat16, decode_layout=E.op_decode_swizzle8(q))
     torch.cuda.synchronize()
     assert torch.equal(out_dl, out)
+    if N > 8192 and M > 8 and epi in (4, 6):
+        # ... and the stream kernel's e4m3 form gives the K-split kernel's bits (chunks of <= 8 rows never take the stream kernel)
+        chunks = torch.cat([E.op_gemm_fp8(epi, X[i:i + 8].bfloat16().cuda().contiguous(), q, sc, out_dtype=torch.float32 if epi == 6 else torch.bfloat16) for i in range(0, M, 8)])
+        torch.cuda.synchronize()
+        assert torch.equal(chunks, out)
     acc = X @ W.t()
     if epi == 7:                                               # fp32 K-slices: their sum is the product
         got = out.reshape(8, M, N).sum(dim=0).cpu()
