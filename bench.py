@@ -339,24 +339,27 @@ def main():
     page_px, char_px, ids = make_inputs(wl)
     headline_inputs = (page_px, char_px, ids)
 
-    def step(new_tokens=None, stamps=None, w=None, inputs=None):
+    def step(new_tokens=None, stamps=None, w=None, inputs=None, merged=None):
+        """merged = [inputs, inputs, ...]: the visual stage (with its all-gather) and the splice of SEVERAL consecutive steps of workload `w`, then ONE prefill + decode over all
+        their pages -- the decode batch of a rank fed from several steps (a page's ids do not depend on its batch); returns the pages of all of them, in order."""
         new_tokens = NEW_TOKENS if new_tokens is None else new_tokens
-        if w is not None:                                 # another workload than the headline's (the strong-scaling block)
-            n_pages, mine = w['n_pages'], w['mine']
-            page_px, char_px, ids = inputs
-        else:
-            n_pages, mine, page_px, char_px, ids = wl['n_pages'], wl['mine'], *headline_inputs
-        pseudo_local, _ = model.align_tiles(char_px)                                 # (3 * my char-tile shard, 4096)
-        gathered = all_gather_rows_async(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile, over xGMI ...
-        vit_mine = model.extract_feature(page_px)                                    # ... underneath the owner's page tiles (my pages * 11, 256, 4096)
-        if stamps is not None:
-            torch.cuda.synchronize(); stamps.append(time.perf_counter())
-        pseudo_all = gathered()
         embeds = []
-        for j, p in enumerate(mine):
-            v = vit_mine[j * PAGE_TILES:(j + 1) * PAGE_TILES]
-            r = pseudo_all[p * CHAR_TILES:(p + 1) * CHAR_TILES]
-            embeds.append(eng.embed_splice(ids[j], v, r, img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID))
+        for one in (merged if merged is not None else [inputs]):
+            if w is not None:                             # another workload than the headline's (the strong-scaling block)
+                n_pages, mine = w['n_pages'], w['mine']
+                page_px, char_px, ids = one
+            else:
+                n_pages, mine, page_px, char_px, ids = wl['n_pages'], wl['mine'], *headline_inputs
+            pseudo_local, _ = model.align_tiles(char_px)                                 # (3 * my char-tile shard, 4096)
+            gathered = all_gather_rows_async(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile, over xGMI ...
+            vit_mine = model.extract_feature(page_px)                                    # ... underneath the owner's page tiles (my pages * 11, 256, 4096)
+            if stamps is not None:
+                torch.cuda.synchronize(); stamps.append(time.perf_counter())
+            pseudo_all = gathered()
+            for j, p in enumerate(mine):
+                v = vit_mine[j * PAGE_TILES:(j + 1) * PAGE_TILES]
+                r = pseudo_all[p * CHAR_TILES:(p + 1) * CHAR_TILES]
+                embeds.append(eng.embed_splice(ids[j], v, r, img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID))
         outs = model.generate_pages(embeds, max_new_tokens=new_tokens, eos_token_id=None)
         assert all(len(o) == new_tokens for o in outs)
         if stamps is not None:
@@ -524,6 +527,24 @@ def main():
             torch.cuda.synchronize()
         same_share = bool(share_out == full_out[:n_own])
         vis_ms, pre_ms = (st3[1] - st3[0]) * 1e3, (st3[2] - st3[1]) * 1e3
+        # The same rank with its decode batch fed from TWO consecutive steps: visual stage + splice of step A, of step B, then one prefill and ONE decode over both steps'
+        # pages (16 rows per rank at 64 pages over 8): the weights are streamed once per two steps' pages.  Throughput view of the same configuration (two steps in
+        # flight, as PagePipeline keeps them at N = 1), measurable on one GPU like the share itself; per-step time = the merged pass / 2.
+        merged2 = None
+        if 2 * n_own <= args.pages and 2 * n_own <= 64:
+            ins2 = [(page_px[k * n_own * PAGE_TILES:(k + 1) * n_own * PAGE_TILES], char_px[k * n_ct:(k + 1) * n_ct], ids[k * n_own:(k + 1) * n_own]) for k in range(2)]
+            step(w=w_share, merged=ins2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m_out = step(w=w_share, merged=ins2)
+            torch.cuda.synchronize()
+            t_m = (time.perf_counter() - t0) / 2
+            merged2 = {'what': f'two consecutive steps of that share with ONE decode over both steps\' pages ({2 * n_own} rows per rank instead of {n_own}): visual stage + splice of step A, of step B, '
+                               'one prefill, one decode; a page\'s ids do not depend on its batch',
+                       'ms_per_step': round(t_m * 1e3, 2), f'projected_speedup_{args.share_world}': round(full_ms / (t_m * 1e3), 3),
+                       'ids_equal_the_same_pages_of_the_full_step': bool(m_out == full_out[:2 * n_own]),
+                       'note': 'a throughput arrangement (a page waits for the next step\'s pages before it decodes); the one-batch-at-a-time share above is the latency view'}
+            del ins2
         strong_share = {
             'what': f'one rank\'s share of BASELINE config 4 as written ({args.pages} pages per step over {args.share_world} GPUs, plan_workload(strong, rank 0)) run ALONE on this one GPU, '
                     f'one batch at a time: {n_own} pages owned ({n_own * PAGE_TILES} page tiles, {n_own} prompts of {S_page} tokens, {NEW_TOKENS - 1} decode steps of {n_own} rows) '
@@ -540,7 +561,8 @@ def main():
             'projection_note': f'upper bound: ms of the {args.pages}-page step on one GPU / ms of one rank\'s share; excludes the all-gather (24.5 KB per character tile, '
                                'started under the page tiles\' ViT) and rank skew (every rank has the same tile and page counts at 64 pages over 8); '
                                'the second ratio is against the headline N = 1 step (two batches in flight)',
-            'ids_equal_the_same_pages_of_the_full_step': same_share}
+            'ids_equal_the_same_pages_of_the_full_step': same_share,
+            'two_steps_one_decode': merged2}
         del ins
 
     # ---- N > 1, weak scaling (what the driver's one command runs): BASELINE config 4 AS WRITTEN in the same process group ----
@@ -568,6 +590,17 @@ def main():
         el, vis_s, pre_s = (float(x) for x in t.tolist())
         g2 = gather_standalone(ws)
         per_step = el / args.strong_steps
+        # the same with every rank's decode batch fed from two consecutive steps (strong_share.two_steps_one_decode at N = 1): two visual stages + gathers, one decode
+        merged_ms = None
+        if 2 * ws['pages_per_gpu'] <= 64:
+            step(w=ws, merged=[ins, ins])
+            sync()
+            t0 = time.perf_counter()
+            step(w=ws, merged=[ins, ins])
+            sync()
+            tm = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            merged_ms = float(tm.item()) / 2 * 1e3
         strong = {'what': 'BASELINE config 4 as written: the pages of a step are divided over the ranks (strong scaling), one batch at a time, in the same process group '
                           'as the weak-scaling line above',
                   'scaling': 'strong', 'pages_per_step': ws['n_pages'], 'pages_per_gpu': ws['pages_per_gpu'], 'char_tiles_this_rank': ws['ct_hi'] - ws['ct_lo'],
@@ -576,6 +609,9 @@ def main():
                                 'decode_remaining_tokens': round(max(per_step - vis_s - pre_s, 0.0) * 1e3, 1),
                                 'how': 'MAX over ranks of one extra stamped pass that stops after the first token; decode = timed step - those two'},
                   'all_gather': g2,
+                  'two_steps_one_decode': None if merged_ms is None else {
+                      'what': 'two consecutive steps with ONE decode over both steps\' pages per rank (the weights are streamed once per two steps\' pages): a throughput arrangement',
+                      'ms_per_step': round(merged_ms, 2), 'value': round(ws['n_pages'] / (merged_ms * 1e-3), 4), 'unit': 'pages/s'},
                   'n1_denominator': ((f'the N = 1 line of `python bench.py --gpus 1 --pages {ws["n_pages"]}` is this configuration on one GPU'
                                       + (' (= the default N = 1 line)' if ws['n_pages'] == 64 and args.pages == 64 else '')
                                       + ': speed-up = this value / that value; none is printed here because this run did not measure N = 1'))}
