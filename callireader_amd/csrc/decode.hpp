@@ -25,7 +25,7 @@ struct DecodeGemmParams {
     bf16 *q_out, *kc, *vc;
     const int32_t *seqs, *lens;
     int max_tokens;
-    int flags;                           // reserved for tuning knobs (cr_op_decode_gemm / CR_DEC_FLAGS); none at present
+    int flags;                           // tuning knobs (cr_op_decode_gemm / CR_DEC_FLAGS): bit 0 forces, bit 1 forbids the one-wave-per-row RMSNorm prologue of w1|w3 / the LM head
 };
 
 bool decode_fused_supported(int M, int ff);

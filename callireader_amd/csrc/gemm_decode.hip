@@ -47,11 +47,15 @@ enum { DEPI_ROPE = 100 };
 // SW: the weights come in the decode layout (decode_swizzle_kernel below): one 1 KiB block per (16-row tile, 32-deep k-step), lane l's 16 bytes at l * 16 --
 //     a wave's load instruction reads ONE contiguous KiB instead of 16 rows x 64 bytes (scripts/ubench/persist_stream.hip: the four streams of a layer take
 //     68.5 us contiguous against 83.6 us row-wise; the same values in the same registers, so not a bit changes).
-template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false, bool SW = false>
-__global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(const DecodeGemmParams p) {      // PRO forms: 128 registers, 16 waves per CU
+// PROW: the RMSNorm prologue with ONE WAVE PER ROW (lane l holds the row's thread slots l, l + 64, l + 128, l + 192 of norm.hip's layout: the same slot sums, the same
+//     butterfly over the lane index, the same ((W0 + W1) + W2) + W3 -- the same bits) instead of 256 threads per row: no barrier inside, every row at once (M <= waves), where
+//     the 256-thread form takes M / (threads / 256) rounds of two barriers each.  The packed row beside the weight batch in flight needs more than 128 registers (at 128 it
+//     spilled 16-24 and lost, profiles/round5/03_*), so these instances are built for two waves per SIMD -- which is all the w1|w3 / LM-head grids ever put on a CU.
+template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false, bool SW = false, bool PROW = false>
+__global__ __launch_bounds__(TG * KW * 64, (PRO && !PROW) ? 4 : 2) void gemm_decode_kernel(const DecodeGemmParams p) {      // PRO forms: 128 registers, 16 waves per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = VS * KPR;            // 32-deep k-steps per wave and tile
-    constexpr int UB = 8;                  // k-steps per register batch; two batches of weight loads are in flight
+    constexpr int UB = 8;                  // k-steps per register batch; two batches of weight loads are in flight (batches of 16 in the 256-register forms: +-0, round 5)
     static_assert(T % UB == 0 && T / UB >= 2, "whole batches, at least two");
     static_assert(!ALIAS || (PRO && TG == 1), "aliasing is for the one-tile-per-workgroup prologue form");
     constexpr int NB = T / UB;
@@ -113,7 +117,33 @@ __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(
         cs = bf2f(p.cosT[(int64_t)pos * HD + c]); sn = bf2f(p.sinT[(int64_t)pos * HD + c]);
     }
 
-    if (PRO) {
+    if (PRO && PROW) {
+        if (wave < p.M) {                                         // wave-uniform; the row stays packed (32 registers) between the two passes
+            const bf16* xr_ = p.xres + (int64_t)wave * D4;
+            bf16x8 raw[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { raw[q][0] = *(const bf16x8*)(xr_ + (q * 64 + lane) * 16); raw[q][1] = *(const bf16x8*)(xr_ + (q * 64 + lane) * 16 + 8); }
+            float wsum[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float x[16];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { x[e] = bf2f(raw[q][0][e]); x[8 + e] = bf2f(raw[q][1][e]); }
+                wsum[q] = wave_sum(rms_sumsq16(x));
+            }
+            const float tot = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float x[16], y[16];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { x[e] = bf2f(raw[q][0][e]); x[8 + e] = bf2f(raw[q][1][e]); }
+                rms_apply16(x, tot, p.eps, p.gamma + (q * 64 + lane) * 16, y);
+                store16((bf16*)(xlds + (size_t)wave * XROW) + (q * 64 + lane) * 16, y);
+            }
+        }
+        __syncthreads();
+        load_w(wr[1], wp, 1);
+    } else if (PRO) {
         // RMSNorm of the M residual rows into LDS (measured and dropped: one wave per row without barriers -- the row held in registers
         // beside the weight loads spills at 128 registers, re-reading it costs a second round trip: 18.7 against 16.4 us for wqkv at one row)
         constexpr int NG = NTHREADS / 256;                        // 256 threads per row: norm.hip's own layout and function
@@ -230,21 +260,23 @@ __global__ __launch_bounds__(TG * KW * 64, PRO ? 4 : 2) void gemm_decode_kernel(
 template <int KW, int VS, int TG>
 constexpr int fixed_lds() { return TG * (KW * VS + 1) * LIN_FLOATS * 4 + 64; }
 
-template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false, bool SW = false>
+template <int EPI, int KW, int VS, int KPR, bool PRO, int TG = 1, bool ALIAS = false, bool SW = false, bool PROW = false>
 int launch_one(const DecodeGemmParams& p, int grid_cap, hipStream_t st) {
-    if (!SW && p.swizzled) return launch_one<EPI, KW, VS, KPR, PRO, TG, ALIAS, true>(p, grid_cap, st);
+    if (!SW && p.swizzled) return launch_one<EPI, KW, VS, KPR, PRO, TG, ALIAS, true, PROW>(p, grid_cap, st);
+    static_assert(!PROW || PRO, "one wave per row is a prologue form");
+    if (PROW && p.M > TG * KW) return CR_ERR_ARG;
     const int ntiles = (p.N + 15) / 16;
     const int sets = (ntiles + TG - 1) / TG;
     const int xbytes = PRO ? p.M * (p.K * 2 + 16) : 0;
     const int lds = ALIAS ? (xbytes + 64 > fixed_lds<KW, VS, TG>() ? xbytes + 64 : fixed_lds<KW, VS, TG>()) : fixed_lds<KW, VS, TG>() + xbytes;
     if (lds > 160 * 1024 || (ALIAS && grid_cap != 0)) return CR_ERR_ARG;
     static std::atomic<uint64_t> attr_done{0};
-    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW>, 160 * 1024)) return CR_ERR_HIP;
+    if (!cr_dyn_lds_once(attr_done, (const void*)gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW, PROW>, 160 * 1024)) return CR_ERR_HIP;
     const int grid = grid_cap > 0 && grid_cap < sets ? grid_cap : sets;
     // the look-ahead across a tile boundary leaves the next tile's batches 0 / 1 in wr[(NB - 2) & 1] / wr[(NB - 1) & 1]: right for an even number of batches only,
     // so an odd one (w2: 7) must never walk a second tile
     if ((VS * KPR / 8) % 2 != 0 && grid < sets) return CR_ERR_ARG;
-    hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW>), dim3(grid), dim3(TG * KW * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_decode_kernel<EPI, KW, VS, KPR, PRO, TG, ALIAS, SW, PROW>), dim3(grid), dim3(TG * KW * 64), lds, st, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }
 
@@ -326,23 +358,36 @@ static int launch_decode_gemm_(int which, const DecodeGemmParams& p, hipStream_t
     // count (w1|w3 at one row, us: 256 -> 43.6, 512 -> 42.5, 640 -> 46.4, 768 -> 43.3, 896 -> 47.9, 1024 -> 42.9, 1792 -> 44.3; at eight rows 49.8 / 51.2 for 512 / 896):
     // every workgroup repeats the RMSNorm prologue, and a grid that is not a multiple of the 256 CUs leaves some of them a workgroup short
     static const int g13 = env_int("CR_DEC_GRID13", 512), ghead = env_int("CR_DEC_GRIDHEAD", 512);
+    // one wave per row in the RMSNorm prologue of w1|w3 and the LM head from 3 rows on (round 5, profiles/round5/15_*; us per launch, 256 threads per row -> one wave per row:
+    // w1|w3 38.1 -> 38.3 at 2 rows, 40.4 -> 38.0 at 4, 42.0 -> 41.3 at 5, 43.7 -> 41.9 at 8; one row 36.8 -> 38.1: the single round of the 256-thread form is the shorter one there);
+    // flags bit 0 forces it, bit 1 forbids it (A/B)
+    const bool prow = ((p.M >= 3) || (p.flags & 1)) && !(p.flags & 2);
     switch (which) {
         case DEC_WQKV:
             if (p.N != 6144 || p.K != 4096 || !p.xres || !p.gamma || !p.cosT || !p.sinT || !p.q_out || !p.kc || !p.vc || !p.seqs || !p.lens) return CR_ERR_ARG;
+            // (one wave per row here too -- which costs the second workgroup per CU its registers -- measured 15.1-17.2 us against 11.2-15.5 at 1-8 rows: not kept)
             return launch_one<DEPI_ROPE, 8, DEC_SLICES_WQKV, 8, true, 1, true>(p, 0, st);              // one tile per workgroup: sums alias the normalised rows
         case DEC_WO:
             if (p.N != 4096 || p.K != 4096 || !p.X || !p.xio) return CR_ERR_ARG;
             return launch_one<EPI_RES, 8, DEC_SLICES_WO, 4, false>(p, 0, st);
         case DEC_W13:
             if (p.N != 2 * 14336 || p.K != 4096 || !p.xres || !p.gamma || !p.C) return CR_ERR_ARG;
-            if (p.M > 4) return launch_one<EPI_SWIGLU, 4, 1, 32, true, 2>(p, g13 / 2, st);      // two tiles at a time on shared rows: 16 waves per CU at 5..8 rows
+            if (p.M > 4) {
+                if (prow) return launch_one<EPI_SWIGLU, 4, 1, 32, true, 2, false, false, true>(p, g13 / 2, st);
+                return launch_one<EPI_SWIGLU, 4, 1, 32, true, 2>(p, g13 / 2, st);      // two tiles at a time on shared rows: 16 waves per CU at 5..8 rows
+            }
+            if (prow) return launch_one<EPI_SWIGLU, 4, 1, 32, true, 1, false, false, true>(p, g13, st);
             return launch_one<EPI_SWIGLU, 4, 1, 32, true>(p, g13, st);
         case DEC_W2:
             if (p.N != 4096 || p.K != 14336 || !p.X || !p.xio) return CR_ERR_ARG;
             return launch_one<EPI_RES, 8, DEC_SLICES_W2, 14, false>(p, 0, st);
         case DEC_HEAD:
             if (p.K != 4096 || !p.xres || !p.gamma || !p.C) return CR_ERR_ARG;
-            if (p.M > 4) return launch_one<EPI_F32, 4, 1, 32, true, 2>(p, ghead / 2, st);
+            if (p.M > 4) {
+                if (prow) return launch_one<EPI_F32, 4, 1, 32, true, 2, false, false, true>(p, ghead / 2, st);
+                return launch_one<EPI_F32, 4, 1, 32, true, 2>(p, ghead / 2, st);
+            }
+            if (prow) return launch_one<EPI_F32, 4, 1, 32, true, 1, false, false, true>(p, ghead, st);
             return launch_one<EPI_F32, 4, 1, 32, true>(p, ghead, st);
     }
     return CR_ERR_ARG;
