@@ -822,6 +822,20 @@ def main():
             t0 = time.perf_counter()
             step(); torch.cuda.synchronize()
             dt_step8 = time.perf_counter() - t0
+            # BASELINE config 5 is config 4 with the fp8 weight path: the same rank-0 share as `strong_share`, both sides with the fp8 options on
+            share8 = None
+            if strong_share is not None:
+                w8s = plan_strong_share(args.pages, args.share_world)
+                ins8 = (page_px[:w8s['pages_per_gpu'] * PAGE_TILES], char_px[:w8s['ct_hi']], ids[:w8s['pages_per_gpu']])
+                step(w=w8s, inputs=ins8); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.share_steps):
+                    step(w=w8s, inputs=ins8)
+                torch.cuda.synchronize()
+                t_s8 = (time.perf_counter() - t0) / args.share_steps
+                share8 = {'what': 'strong_share with the fp8 options on (level 2 + e4m3-weight decode) against the fp8 step above: config 5\'s per-rank share',
+                          't_share_ms': round(t_s8 * 1e3, 2), 'full_step_ms': round(dt_step8 * 1e3, 1), f'projected_speedup_{args.share_world}': round(dt_step8 / t_s8, 3)}
+                del ins8
             eng.enable_fp8_mfma(False)
             eng.enable_fp8_decode(False)
             result['fp8_mfma'] = {'what': 'one whole step (one batch at a time) with cr_enable_fp8_mfma level 2 and cr_enable_fp8_decode (e4m3 weight copies in their decode layout): ViT QKV / fc1 / fc2, mlp1[1] and all four LLM '
@@ -829,7 +843,7 @@ def main():
                                           'LayerNorm-derived bound, or from a quantiser pass; per-row weight scales; fp32 accumulation); ViT proj, attention, '
                                           'resampler, VQ, KV cache stay bf16: an option, not the headline',
                                   'pages_per_s': round(n_pages / dt_step8, 4), 'ms_per_step': round(dt_step8 * 1e3, 1),
-                                  'level1_only_pages_per_s': round(n_pages / dt_step8_l1, 4),
+                                  'level1_only_pages_per_s': round(n_pages / dt_step8_l1, 4), 'strong_share': share8,
                                   'accuracy': 'NOT parity-preserving on random-init weights (profiles/round3/full_depth_parity.json: fp8_mfma_full_depth; peaked_streams.json: fp8); the gate on a real checkpoint is evaluate.py --compare_fp8', 'speedup_vs_bf16_step_one_batch_at_a_time': round((seq_ms if seq_ms else ms_per_step) / (dt_step8 * 1e3), 3),
                                   'visual_ms': round((st8[1] - st8[0]) * 1e3, 1), 'prefill_ms': round((st8[2] - st8[1]) * 1e3, 1),
                                   'parity': 'tests/test_gpu_fp8_mfma.py: exact on e4m3-representable data; model-level difference to the bf16 path stated there'}
