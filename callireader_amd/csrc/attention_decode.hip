@@ -14,6 +14,7 @@
 // reference's (bf16, / sqrt(128), bf16); each 16-lane group keeps ITS 16 keys' scores, so its softmax needs no running maximum (one exponential per lane and
 // key: lane c computes query head c & 3, the quad shares them by DPP); P.V by fp32 FMAs on bf16-rounded probabilities.  The 16 (wave, group) partials of the
 // workgroup meet in LDS and are merged in index order: a row's result depends on its own key count only, never on the batch.
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "attention.hpp"
@@ -168,7 +169,8 @@ bool decode_attn_supported(const AttnParams& p, int head_dim) {
     static const bool off = [] { const char* e = getenv("CR_DECODE_ATTN"); return e && e[0] == '0'; }();      // A/B aid: the matrix-core split kernel
     return !off && head_dim == HD && p.Sq == NQ && ATTN_SPLIT_TILES == 4 && p.q_prescale == 1.0f && p.part_ml && p.part_o && p.nsplit > 0 &&
            (p.q_rs & 7) == 0 && (p.q_hs & 7) == 0 && (p.q_bs & 7) == 0 && (p.k_rs & 7) == 0 && (p.v_rs & 7) == 0 && (p.k_hs & 7) == 0 && (p.v_hs & 7) == 0 &&
-           (p.k_bs & 7) == 0 && (p.v_bs & 7) == 0 && (p.sk_arr || p.Sk > 0);
+           (p.k_bs & 7) == 0 && (p.v_bs & 7) == 0 && (p.sk_arr || p.Sk > 0) &&
+           (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.part_o & 7) == 0;      // 16-byte loads, 8-byte partial stores
 }
 
 int launch_decode_attn(const AttnParams& p, hipStream_t stream) {

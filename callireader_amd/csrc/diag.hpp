@@ -10,7 +10,8 @@
 //   * scripts/build_variant.py also hashes the flags into cr_build_id(), so a variant never carries the product's id.
 #pragma once
 
-#define CR_DIAG_WRONG_RESULTS_LIST "CR_BREAK_WAIT CR_KO_STORE CR_KO_WCONTIG CR_KO_AROWS CR_KO_EPI CR_KO_XFRAG CR_KO_VIT_SOFTMAX CR_KO_VIT_MFMA"
+// (wrong results by design: CR_BREAK_WAIT, CR_KO_STORE, CR_KO_WCONTIG, CR_KO_AROWS, CR_KO_EPI, CR_KO_XFRAG, CR_KO_VIT_SOFTMAX, CR_KO_VIT_MFMA; right results, other cost or extra
+//  output: CR_POISON, CR_KI_VALU, CR_DIAG_STAMPS, CR_TILE_GM -- the binding refuses all of them alike)
 
 #ifdef CR_BREAK_WAIT
 #define CR_DIAG_S1 "CR_BREAK_WAIT "
