@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get('CR_HIP_LIB') or os.path.join(os.path.dirname(os.path
 
 CR_OK = 0
 CR_BF16, CR_F32, CR_I64, CR_I32 = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ModelDesc(C.Structure):
@@ -70,6 +70,8 @@ SIGNATURES = {
     'cr_op_decode_swizzle': (i32, [i32, vp, i64, i32, i32, vp, vp]),
     'cr_op_decode_gemm': (i32, [i32, i32, vp, i64, i32, i32, i32, vp, i64, vp, vp, f32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'cr_op_attention': (i32, [vp, vp, vp, vp, C.POINTER(i64), i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]),
+    'cr_op_decode_attention_scratch_floats': (i64, [i32, i32]),
+    'cr_op_decode_attention': (i32, [i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp]),
 }
 
 

@@ -373,4 +373,28 @@ int cr_op_attention(const void* q, const void* k, const void* v, void* o, const 
     return CR_OK;
 }
 
+int64_t cr_op_decode_attention_scratch_floats(int B, int max_keys) {
+    const int nsplit = ((max_keys + 63) / 64 + ATTN_SPLIT_TILES - 1) / ATTN_SPLIT_TILES;
+    return (int64_t)attn_split_ws_floats(B, 8, 4, nsplit, 128);
+}
+
+int cr_op_decode_attention(int which, const void* q, const void* kc, const void* vc, int max_tokens, const int32_t* seqs, const int32_t* lens, int B, int max_keys,
+                           float s_div, float* scratch, void* out, void* stream) {
+    if (!q || !kc || !vc || !seqs || !lens || !scratch || !out || B <= 0 || max_keys <= 0 || max_tokens < max_keys || (which != 0 && which != 1))
+        return cr_fail(CR_ERR_ARG, "cr_op_decode_attention: bad argument");
+    constexpr int HD = 128, NKV = 8, G = 4, D = NKV * G * HD;
+    AttnParams ap{};
+    ap.K = (const bf16*)kc; ap.V = (const bf16*)vc; ap.Q = (const bf16*)q; ap.O = (bf16*)out;
+    ap.k_bs = ap.v_bs = (int64_t)NKV * max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)max_tokens * HD;
+    ap.q_prescale = 1.0f; ap.s_div = s_div;
+    ap.q_bs = D; ap.q_rs = HD; ap.q_hs = G * HD; ap.o_bs = D; ap.o_rs = HD; ap.o_hs = G * HD;
+    ap.B = B; ap.H = NKV; ap.Sq = G; ap.Sk = 0; ap.kv_group = 1; ap.q_pos0 = 0;
+    ap.seq_map = seqs; ap.sk_arr = lens; ap.sk_add = 1;
+    ap.nsplit = ((max_keys + 63) / 64 + ATTN_SPLIT_TILES - 1) / ATTN_SPLIT_TILES;
+    ap.part_ml = scratch; ap.part_o = scratch + (size_t)B * NKV * ap.nsplit * G * 2;
+    ap.q_pos0 = which == 1 ? -1 : 0;                      // (-1: launch_flash_attn_split keeps the matrix-core split kernel, as CR_DECODE_ATTN=0 does for a whole process)
+    if (launch_flash_attn_split(ap, HD, (hipStream_t)stream) != CR_OK) return cr_fail(CR_ERR_HIP, "cr_op_decode_attention: launch failed");
+    return CR_OK;
+}
+
 }  // extern "C"

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 9   /* 9: cr_build_flags, cr_diag_register; 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8, cr_op_gemm bits 18-19; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
+#define CR_ABI_VERSION 10  /* 10: cr_op_decode_attention(+_scratch_floats); 9: cr_build_flags, cr_diag_register; 8: cr_op_decode_swizzle, cr_op_decode_gemm flags bit 8, cr_op_gemm bits 18-19; 7: cr_op_decode_gemm; 6: cr_build_id, cr_llm_hidden_probe; 5: cr_share_weights, cr_op_gemm_q8, cr_op_norm_fp8 takes the next linear's bound; 4: cr_enable_fp8_mfma, cr_op_norm_fp8, cr_op_gemm bit 17; 2: cr_orderformer; cr_op_gemm kernel pin and EPI_PARTIAL (epi 7); 3: cr_profile_stats, cr_kv_read, cr_kv_reset takes a stream, cr_enable_fp8_decode, cr_op_quantize_fp8, epi 8 */
 
 enum { CR_OK = 0, CR_ERR_ARG = -1, CR_ERR_HIP = -2, CR_ERR_STATE = -3, CR_ERR_NOMEM = -4 };
 enum { CR_BF16 = 0, CR_F32 = 1, CR_I64 = 2, CR_I32 = 3, CR_U8 = 4 /* library-internal: e4m3 weight copies */ };
@@ -254,6 +254,15 @@ int cr_op_decode_swizzle(int which, const void* W, int64_t ldw, int N, int K, vo
 int cr_op_attention(const void* q, const void* k, const void* v, void* o, const int64_t* strides12, int B, int H,
                     int Sq, int Sk, int head_dim, int kv_group, int causal, int q_pos0, float q_prescale, float s_div,
                     void* stream);
+
+/* Batched decode attention alone (test / tuning entry; cr_llm_decode drives the same launcher): row b = one new token of cache slot seqs[b], its H_kv x 4 query heads x 128 at
+ * q + b * 4096 (InternLM2's GQA layout: the 4 query heads of KV head h at (4 h .. 4 h + 3) * 128), keys / values [n_slots][8][max_tokens][128] bf16, lens[slot] + 1 keys per row
+ * (the new token's K / V row is already in the cache), scores bf16 -> / s_div -> bf16, fp32 softmax, bf16 probabilities (modeling_internlm2.py:393-410); splits of 256 keys, partials in
+ * `scratch` (cr_op_decode_attention_scratch_floats(B, max_keys) floats), merged in index order.  which = 0: the dispatcher's choice (attention_decode.hip), 1: the matrix-core split
+ * kernel of attention.hip.  seqs / lens are DEVICE arrays.  ABI v10. */
+int64_t cr_op_decode_attention_scratch_floats(int B, int max_keys);
+int cr_op_decode_attention(int which, const void* q, const void* kc, const void* vc, int max_tokens, const int32_t* seqs, const int32_t* lens, int B, int max_keys,
+                           float s_div, float* scratch, void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -599,6 +599,41 @@ def test_attention_vit_two_wave_form_gives_the_four_wave_forms_bits(E, monkeypat
     assert torch.isfinite(ref.float()).all()
 
 
+def test_decode_attention_kernels_against_the_reference_arithmetic(E):
+    """The batched decode attention alone (cr_op_decode_attention): one new token per row over a cache of ragged lengths -- a single key, lengths on both sides of the 64-key
+    wave, the 256-key split and the 4-key lane groups, a long context (5 000 keys: 20 splits), rows in arbitrary cache slots.  Both kernels -- attention_decode.hip's streaming
+    vector-pipe form (the product) and attention.hip's matrix-core split form -- against the reference's rounding points (modeling_internlm2.py:393-410: scores bf16, / sqrt(128)
+    -> bf16, fp32 softmax, bf16 probabilities); the two kernels within one bf16 step of each other; a row's result independent of the batch it is launched in (same bits)."""
+    g = torch.Generator().manual_seed(21)
+    lens = [0, 2, 3, 62, 63, 64, 254, 255, 256, 257, 999, 4999]            # keys = lens + 1
+    slots = [5, 0, 7, 3, 11, 1, 9, 2, 10, 4, 8, 6]
+    n_slots, max_tokens, H, G, D = 12, 5008, 8, 4, 128
+    kc = bf(_rand((n_slots, H, max_tokens, D), g)).to(dev())
+    vc = bf(_rand((n_slots, H, max_tokens, D), g)).to(dev())
+    q = bf(_rand((len(lens), H * G * D), g) * 0.7).to(dev())
+    seqs = torch.tensor(slots, dtype=torch.int32, device=dev())
+    lens_d = torch.zeros(n_slots, dtype=torch.int32, device=dev())
+    lens_d[seqs.long()] = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out = E.op_decode_attention(q, kc, vc, seqs, lens_d)
+    out_mc = E.op_decode_attention(q, kc, vc, seqs, lens_d, which=1)
+    torch.cuda.synchronize()
+    sdiv = math.sqrt(128.0)
+    for b, (L, slot) in enumerate(zip(lens, slots)):
+        qq = q[b].float().reshape(H, G, D)
+        k = kc[slot, :, :L + 1].float()
+        v = vc[slot, :, :L + 1].float()
+        ref = _attn_ref(qq, k, v, False, 0, 1.0, sdiv).reshape(-1)
+        torch.testing.assert_close(out[b].float(), ref, rtol=RTOL, atol=1.5e-2)
+        torch.testing.assert_close(out_mc[b].float(), ref, rtol=RTOL, atol=1.5e-2)
+    assert float((out.float() - out_mc.float()).abs().max()) <= 2 ** -6
+    # batch independence: the last row alone, and the rows in another order, give the same bits
+    alone = E.op_decode_attention(q[-1:].contiguous(), kc, vc, seqs[-1:].contiguous(), lens_d)
+    perm = torch.tensor([3, 11, 0, 7, 5, 1, 9, 2, 10, 4, 8, 6], device=dev())
+    shuffled = E.op_decode_attention(q[perm].contiguous(), kc, vc, seqs[perm].contiguous(), lens_d)
+    torch.cuda.synchronize()
+    assert torch.equal(alone[0], out[-1]) and torch.equal(shuffled, out[perm])
+
+
 def test_attention_exact_identity_layout(E):
     """V = one-hot rows, uniform scores: output row = mean of V rows -> exact in bf16; catches V^T/tr-read mistakes."""
     Bn, S, H, D = 1, 64, 1, 64
