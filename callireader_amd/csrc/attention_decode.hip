@@ -60,22 +60,25 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const AttnParams p)
     }
     const int ksub = lane >> 4, c = lane & 15, own = c & 3;
     const int key0 = split * 256 + wave * 64 + ksub;          // this lane's keys: key0 + 4 i
-    const bf16* Kb = p.K + (int64_t)slot * p.k_bs + (int64_t)head * p.k_hs + c * 8;
-    const bf16* Vb = p.V + (int64_t)slot * p.v_bs + (int64_t)head * p.v_hs + c * 8;
+    // one uniform 64-bit base per (slot, head) plane + a 32-bit per-lane element offset (a plane is max_tokens x 128 elements: far below 2^31): the 64 x 64-bit
+    // products of `key * stride` per load were a fifth of the kernel's vector instructions
+    const bf16* Kb = p.K + (int64_t)slot * p.k_bs + (int64_t)head * p.k_hs;
+    const bf16* Vb = p.V + (int64_t)slot * p.v_bs + (int64_t)head * p.v_hs;
+    const unsigned k_rs = (unsigned)p.k_rs, v_rs = (unsigned)p.v_rs, lane_off = (unsigned)c * 8u;
     // the query rows first, then all 32 K / V loads behind them, and NOTHING else in between: loads return in order, so the first use of q waits for four
     // loads, not for the stream (left to itself the scheduler consumed q before it had issued the stream: a round trip with nothing in flight)
     bf16x8 q[NQ];
     {
-        const bf16* qp = p.Q + (int64_t)batch * p.q_bs + (int64_t)head * p.q_hs + c * 8;
+        const bf16* qp = p.Q + (int64_t)batch * p.q_bs + (int64_t)head * p.q_hs + lane_off;
 #pragma unroll
         for (int h = 0; h < NQ; h++) q[h] = *(const bf16x8*)(qp + (int64_t)h * p.q_rs);
     }
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 kr[IT], vr[IT];
 #pragma unroll
-    for (int i = 0; i < IT; i++) kr[i] = __builtin_nontemporal_load((const bf16x8*)(Kb + (int64_t)min(key0 + 4 * i, Sk - 1) * p.k_rs));
+    for (int i = 0; i < IT; i++) kr[i] = __builtin_nontemporal_load((const bf16x8*)(Kb + ((unsigned)min(key0 + 4 * i, Sk - 1) * k_rs + lane_off)));
 #pragma unroll
-    for (int i = 0; i < IT; i++) vr[i] = __builtin_nontemporal_load((const bf16x8*)(Vb + (int64_t)min(key0 + 4 * i, Sk - 1) * p.v_rs));
+    for (int i = 0; i < IT; i++) vr[i] = __builtin_nontemporal_load((const bf16x8*)(Vb + ((unsigned)min(key0 + 4 * i, Sk - 1) * v_rs + lane_off)));
     __builtin_amdgcn_sched_barrier(0);
     const float inv_div = 1.0f / p.s_div;
 
@@ -170,7 +173,7 @@ bool decode_attn_supported(const AttnParams& p, int head_dim) {
     // (q_pos0 < 0: a caller's request for the matrix-core split kernel, cr_op_decode_attention)
     return !off && p.q_pos0 >= 0 && head_dim == HD && p.Sq == NQ && ATTN_SPLIT_TILES == 4 && p.q_prescale == 1.0f && p.part_ml && p.part_o && p.nsplit > 0 &&
            (p.q_rs & 7) == 0 && (p.q_hs & 7) == 0 && (p.q_bs & 7) == 0 && (p.k_rs & 7) == 0 && (p.v_rs & 7) == 0 && (p.k_hs & 7) == 0 && (p.v_hs & 7) == 0 &&
-           (p.k_bs & 7) == 0 && (p.v_bs & 7) == 0 && (p.sk_arr || p.Sk > 0) &&
+           (p.k_bs & 7) == 0 && (p.v_bs & 7) == 0 && (p.sk_arr || p.Sk > 0) && p.k_rs > 0 && p.v_rs > 0 && p.k_rs < 65536 && p.v_rs < 65536 &&
            (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.part_o & 7) == 0;      // 16-byte loads, 8-byte partial stores
 }
 

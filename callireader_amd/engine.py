@@ -407,14 +407,17 @@ def op_decode_gemm(which, W, M, X=None, xres=None, gamma=None, eps=1e-5, xio=Non
             'cr_op_decode_gemm')
 
 
-def op_decode_attention(q, kc, vc, seqs, lens, s_div=11.313708498984761, which=0):
+def op_decode_attention(q, kc, vc, seqs, lens, s_div=11.313708498984761, which=0, max_keys=None, scratch=None, out=None):
     """cr_op_decode_attention: q (B, 4096) bf16 = one new token per row, kc / vc (n_slots, 8, max_tokens, 128) bf16 caches that already hold the token's own K / V row at
     position lens[slot], seqs / lens int32 device tensors; returns (B, 4096) bf16.  which = 1 pins the matrix-core split kernel (A/B)."""
     Bn = q.shape[0]
     max_tokens = kc.shape[2]
-    max_keys = int(lens.max().item()) + 1
-    scratch = torch.empty(int(B.lib.cr_op_decode_attention_scratch_floats(Bn, max_keys)), device=q.device, dtype=torch.float32)
-    out = torch.empty(Bn, 4096, device=q.device, dtype=torch.bfloat16)
+    if max_keys is None:
+        max_keys = int(lens.max().item()) + 1                      # (a host round trip: benchmarks pass max_keys, scratch and out)
+    if scratch is None:
+        scratch = torch.empty(int(B.lib.cr_op_decode_attention_scratch_floats(Bn, max_keys)), device=q.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(Bn, 4096, device=q.device, dtype=torch.bfloat16)
     B.check(B.lib.cr_op_decode_attention(which, _p(q), _p(kc), _p(vc), max_tokens, _p(seqs), _p(lens), Bn, max_keys, float(s_div), _p(scratch), _p(out), _stream()),
             'cr_op_decode_attention')
     return out
