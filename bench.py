@@ -68,19 +68,27 @@ def build_ids(n_page_tiles, n_char_tiles, text_tokens, img_id, ref_id, seed):
     return torch.cat([head, torch.full((n_page_tiles * 256,), img_id), torch.full((n_char_tiles * 3,), ref_id), tail])
 
 
-def plan_workload(scaling, pages, total_pages, world, rank):
+def plan_workload(scaling, pages, total_pages, world, rank, plan='even'):
     """Which pages and which character tiles one rank handles in a step.  weak: `pages` per GPU whatever N (n_pages = pages * world);
-    strong: `total_pages` per step over all ranks (BASELINE config 4 as written: 64 pages over 8 GPUs).  Pages are owned round-robin,
-    the flat list of character tiles is split contiguously and evenly (callireader_amd/parallel.py).  Pure host arithmetic."""
-    from callireader_amd.parallel import shard_range, owned_pages
-    if scaling not in ('weak', 'strong'):
-        raise ValueError(scaling)
+    strong: `total_pages` per step over all ranks (BASELINE config 4 as written: 64 pages over 8 GPUs).  plan 'even': pages are owned
+    round-robin, the flat list of character tiles is split contiguously and evenly; plan 'balanced' (strong only): fewer ranks own pages
+    and the others take more character tiles (callireader_amd/parallel.py: plan_balanced).  Pure host arithmetic."""
+    from callireader_amd.parallel import shard_range, owned_pages, plan_balanced
+    if scaling not in ('weak', 'strong') or plan not in ('even', 'balanced'):
+        raise ValueError((scaling, plan))
     n_pages = total_pages if scaling == 'strong' else pages * world
+    if plan == 'balanced':
+        if scaling != 'strong':
+            raise ValueError('the balanced plan is a strong-scaling plan')
+        pb = plan_balanced(n_pages, world, PAGE_TILES, CHAR_TILES, PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS, NEW_TOKENS)
+        lo, hi = pb['char_bounds'][rank]
+        return {'scaling': scaling, 'plan': 'balanced', 'n_pages': n_pages, 'mine': pb['pages'][rank], 'ct_lo': lo, 'ct_hi': hi, 'ct_counts': pb['char_counts'],
+                'pages_per_gpu': len(pb['pages'][rank]), 'balanced': pb}
     if n_pages < world:
         raise SystemExit(f'{n_pages} pages per step < {world} ranks: every rank needs a page')
     mine = owned_pages(n_pages, world, rank)
     ct_lo, ct_hi = shard_range(n_pages * CHAR_TILES, world, rank)
-    return {'scaling': scaling, 'n_pages': n_pages, 'mine': mine, 'ct_lo': ct_lo, 'ct_hi': ct_hi, 'pages_per_gpu': len(mine)}
+    return {'scaling': scaling, 'plan': 'even', 'n_pages': n_pages, 'mine': mine, 'ct_lo': ct_lo, 'ct_hi': ct_hi, 'pages_per_gpu': len(mine)}
 
 
 def plan_strong_share(total_pages, share_world):
@@ -333,8 +341,9 @@ def main():
     # character tiles (90 % of the visual work) are sharded evenly over all ranks whatever page they belong to;
     # page tiles stay with the page's owner: their embeddings are 2.1 MB per tile and nobody else needs them
     def make_inputs(w):
-        return (synthetic.make_pixels(len(w['mine']) * PAGE_TILES, seed=10 + rank, device=dev),
-                synthetic.make_pixels(w['ct_hi'] - w['ct_lo'], seed=20 + rank, device=dev),
+        def px(n, seed):                                   # (a rank of the balanced plan may own no page, or encode no character tile)
+            return synthetic.make_pixels(n, seed=seed, device=dev) if n else torch.empty((0, 3, 448, 448), dtype=torch.bfloat16, device=dev)
+        return (px(len(w['mine']) * PAGE_TILES, 10 + rank), px(w['ct_hi'] - w['ct_lo'], 20 + rank),
                 [build_ids(PAGE_TILES, CHAR_TILES, TEXT_TOKENS, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, 1000 + p).to(dev) for p in w['mine']])
     page_px, char_px, ids = make_inputs(wl)
     headline_inputs = (page_px, char_px, ids)
@@ -350,9 +359,16 @@ def main():
                 page_px, char_px, ids = one
             else:
                 n_pages, mine, page_px, char_px, ids = wl['n_pages'], wl['mine'], *headline_inputs
-            pseudo_local, _ = model.align_tiles(char_px)                                 # (3 * my char-tile shard, 4096)
-            gathered = all_gather_rows_async(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES)   # 24.5 KB per tile, over xGMI ...
-            vit_mine = model.extract_feature(page_px)                                    # ... underneath the owner's page tiles (my pages * 11, 256, 4096)
+            if char_px.shape[0]:
+                pseudo_local, _ = model.align_tiles(char_px)                             # (3 * my char-tile shard, 4096)
+            else:                                                                        # balanced plan: a rank whose pages already fill its step
+                pseudo_local = torch.empty((0, dims.llm_hidden), dtype=torch.bfloat16, device=dev)
+            if w is not None and w.get('pseudo_all') is not None:                        # one-GPU stand-in for the gather of a share that does not encode all of its
+                gathered = (lambda t: (lambda: t))(w['pseudo_all'])                      # pages' character tiles itself (strong_share.balanced): handed in, made earlier
+            else:
+                gathered = all_gather_rows_async(pseudo_local.reshape(-1, 3, dims.llm_hidden), n_pages * CHAR_TILES,      # 24.5 KB per tile, over xGMI ...
+                                                 counts=None if w is None else w.get('ct_counts'))
+            vit_mine = model.extract_feature(page_px) if len(mine) else None             # ... underneath the owner's page tiles (my pages * 11, 256, 4096)
             if stamps is not None:
                 torch.cuda.synchronize(); stamps.append(time.perf_counter())
             pseudo_all = gathered()
@@ -360,7 +376,7 @@ def main():
                 v = vit_mine[j * PAGE_TILES:(j + 1) * PAGE_TILES]
                 r = pseudo_all[p * CHAR_TILES:(p + 1) * CHAR_TILES]
                 embeds.append(eng.embed_splice(ids[j], v, r, img_id=IMG_CONTEXT_TOKEN_ID, ref_id=ALIGNED_TOKEN_ID))
-        outs = model.generate_pages(embeds, max_new_tokens=new_tokens, eos_token_id=None)
+        outs = model.generate_pages(embeds, max_new_tokens=new_tokens, eos_token_id=None) if embeds else []      # (no pages: a tile-only rank of the balanced plan)
         assert all(len(o) == new_tokens for o in outs)
         if stamps is not None:
             torch.cuda.synchronize(); stamps.append(time.perf_counter())
@@ -545,6 +561,57 @@ def main():
                        'ids_equal_the_same_pages_of_the_full_step': bool(m_out == full_out[:2 * n_own]),
                        'note': 'a throughput arrangement (a page waits for the next step\'s pages before it decodes); the one-batch-at-a-time share above is the latency view'}
             del ins2
+        # The same 64 pages over 8 GPUs under the BALANCED plan (parallel.plan_balanced): fewer ranks own pages (fatter decode batches: the weights are
+        # streamed once per step whatever the rows), the others encode more character tiles.  Two kinds of rank, each timed alone on this GPU: the page owner
+        # with the most work (its pages' other character tiles come out of the all-gather: made beforehand, handed in) and the rank with the most tiles.
+        balanced = None
+        wb0 = plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced')
+        pb = wb0['balanced']
+        if pb['k'] < args.share_world:
+            ra = max(range(args.share_world), key=lambda r: (len(pb['pages'][r]), pb['char_counts'][r], -r))
+            rb = max(range(args.share_world), key=lambda r: (pb['char_counts'][r], -r))
+            nA, cA, cB = len(pb['pages'][ra]), pb['char_counts'][ra], pb['char_counts'][rb]
+
+            def timed_share(w, ins_):
+                step(w=w, inputs=ins_)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                out_ = None
+                for _ in range(args.share_steps):
+                    out_ = step(w=w, inputs=ins_)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / args.share_steps * 1e3, out_
+            pseudo_a, _ = model.align_tiles(char_px[:nA * CHAR_TILES])                   # what the gather hands rank A for its pages
+            w_a = {'n_pages': nA, 'mine': list(range(nA)), 'pseudo_all': pseudo_a.reshape(-1, 3, dims.llm_hidden)}
+            t_a, out_a = timed_share(w_a, (page_px[:nA * PAGE_TILES], char_px[:cA], ids[:nA]))
+            st4 = [0.0]
+            torch.cuda.synchronize(); st4[0] = time.perf_counter()
+            step(new_tokens=1, stamps=st4, w=w_a, inputs=(page_px[:nA * PAGE_TILES], char_px[:cA], ids[:nA]))
+            same_a = bool(out_a == full_out[:nA])
+            del pseudo_a, w_a
+            t_b = None
+            if not pb['pages'][rb]:
+                w_b = {'n_pages': 0, 'mine': [], 'pseudo_all': torch.empty((0, 3, dims.llm_hidden), dtype=torch.bfloat16, device=dev)}
+                t_b, _ = timed_share(w_b, (page_px[:0], char_px[:cB], []))
+            t_bal = max(t_a, t_b or 0.0)
+            balanced = {
+                'what': f'the same {args.pages} pages over {args.share_world} GPUs under parallel.plan_balanced: {pb["k"]} ranks own the pages ({nA} rows per decode batch instead of {n_own}; '
+                        'the decode streams the 14.7 GB of weights once per step whatever the rows), all ranks share the character tiles in uneven contiguous shards, still ONE all-gather; '
+                        'the two kinds of rank timed alone on this GPU, one batch at a time',
+                'plan': {'page_owners': pb['k'], 'pages_per_rank': [len(x) for x in pb['pages']], 'char_tiles_per_rank': pb['char_counts'],
+                         'predicted_ms_per_rank': pb['predicted_ms'], 'predicted_even_plan_ms': pb['predicted_even_ms'],
+                         'cost_model': 'callireader_amd/parallel.py: MI355X_COST (ms per tile, per prompt token, per decode step by rows), measured in profiles/round5'},
+                'page_owner_rank': {'rank': ra, 'pages_owned': nA, 'char_tiles': cA, 't_ms': round(t_a, 2),
+                                    'phases_ms': {'visual': round((st4[1] - st4[0]) * 1e3, 1), 'splice_prefill_first_token': round((st4[2] - st4[1]) * 1e3, 1),
+                                                  'decode_remaining_tokens': round(max(t_a - (st4[2] - st4[0]) * 1e3, 0.0), 1),
+                                                  'decode_ms_per_step': round(max(t_a - (st4[2] - st4[0]) * 1e3, 0.0) / max(NEW_TOKENS - 1, 1), 4)},
+                                    'ids_equal_the_same_pages_of_the_full_step': same_a},
+                'tile_rank': None if t_b is None else {'rank': rb, 'pages_owned': 0, 'char_tiles': cB, 't_ms': round(t_b, 2)},
+                't_step_ms': round(t_bal, 2),
+                f'projected_speedup_{args.share_world}': round(full_ms / t_bal, 3),
+                f'projected_speedup_{args.share_world}_vs_pipelined_n1': round((elapsed / args.steps * 1e3) / t_bal, 3),
+                'projection_note': 'ms of the one-GPU step / ms of the slower kind of rank; excludes the all-gather (uneven shards padded to the largest: '
+                                   f'{args.share_world} x {max(pb["char_counts"])} x 24.5 KB received per rank) and assumes the other ranks of a kind take as long as the one timed'}
         strong_share = {
             'what': f'one rank\'s share of BASELINE config 4 as written ({args.pages} pages per step over {args.share_world} GPUs, plan_workload(strong, rank 0)) run ALONE on this one GPU, '
                     f'one batch at a time: {n_own} pages owned ({n_own * PAGE_TILES} page tiles, {n_own} prompts of {S_page} tokens, {NEW_TOKENS - 1} decode steps of {n_own} rows) '
@@ -562,7 +629,8 @@ def main():
                                'started under the page tiles\' ViT) and rank skew (every rank has the same tile and page counts at 64 pages over 8); '
                                'the second ratio is against the headline N = 1 step (two batches in flight)',
             'ids_equal_the_same_pages_of_the_full_step': same_share,
-            'two_steps_one_decode': merged2}
+            'two_steps_one_decode': merged2,
+            'balanced': balanced}
         del ins
 
     # ---- N > 1, weak scaling (what the driver's one command runs): BASELINE config 4 AS WRITTEN in the same process group ----
@@ -601,6 +669,26 @@ def main():
             tm = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             merged_ms = float(tm.item()) / 2 * 1e3
+        # ... and under the balanced plan (parallel.plan_balanced: fewer page owners, uneven character-tile shards, the same one all-gather)
+        bal = None
+        wbal = plan_workload('strong', args.pages, args.total_pages, world, rank, plan='balanced')
+        if wbal['balanced']['k'] < world and max(len(x) for x in wbal['balanced']['pages']) <= P:
+            ins_b = make_inputs(wbal)
+            step(w=wbal, inputs=ins_b)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.strong_steps):
+                step(w=wbal, inputs=ins_b)
+            sync()
+            tb = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            bal_ms = float(tb.item()) / args.strong_steps * 1e3
+            pb = wbal['balanced']
+            bal = {'what': 'the same step under parallel.plan_balanced: fewer ranks own pages (fatter decode batches), the others encode more character tiles; one all-gather with uneven shards',
+                   'page_owners': pb['k'], 'pages_per_rank': [len(x) for x in pb['pages']], 'char_tiles_per_rank': pb['char_counts'],
+                   'predicted_ms_per_rank': pb['predicted_ms'], 'predicted_even_plan_ms': pb['predicted_even_ms'],
+                   'steps': args.strong_steps, 'ms_per_step': round(bal_ms, 2), 'value': round(wbal['n_pages'] / (bal_ms * 1e-3), 4), 'unit': 'pages/s'}
+            del ins_b
         strong = {'what': 'BASELINE config 4 as written: the pages of a step are divided over the ranks (strong scaling), one batch at a time, in the same process group '
                           'as the weak-scaling line above',
                   'scaling': 'strong', 'pages_per_step': ws['n_pages'], 'pages_per_gpu': ws['pages_per_gpu'], 'char_tiles_this_rank': ws['ct_hi'] - ws['ct_lo'],
@@ -612,6 +700,7 @@ def main():
                   'two_steps_one_decode': None if merged_ms is None else {
                       'what': 'two consecutive steps with ONE decode over both steps\' pages per rank (the weights are streamed once per two steps\' pages): a throughput arrangement',
                       'ms_per_step': round(merged_ms, 2), 'value': round(ws['n_pages'] / (merged_ms * 1e-3), 4), 'unit': 'pages/s'},
+                  'balanced': bal,
                   'n1_denominator': ((f'the N = 1 line of `python bench.py --gpus 1 --pages {ws["n_pages"]}` is this configuration on one GPU'
                                       + (' (= the default N = 1 line)' if ws['n_pages'] == 64 and args.pages == 64 else '')
                                       + ': speed-up = this value / that value; none is printed here because this run did not measure N = 1'))}

@@ -174,6 +174,7 @@ bool decode_attn_supported(const AttnParams& p, int head_dim) {
     return !off && p.q_pos0 >= 0 && head_dim == HD && p.Sq == NQ && ATTN_SPLIT_TILES == 4 && p.q_prescale == 1.0f && p.part_ml && p.part_o && p.nsplit > 0 &&
            (p.q_rs & 7) == 0 && (p.q_hs & 7) == 0 && (p.q_bs & 7) == 0 && (p.k_rs & 7) == 0 && (p.v_rs & 7) == 0 && (p.k_hs & 7) == 0 && (p.v_hs & 7) == 0 &&
            (p.k_bs & 7) == 0 && (p.v_bs & 7) == 0 && (p.sk_arr || p.Sk > 0) && p.k_rs > 0 && p.v_rs > 0 && p.k_rs < 65536 && p.v_rs < 65536 &&
+           (int64_t)p.nsplit * 256 * (p.k_rs > p.v_rs ? p.k_rs : p.v_rs) < (1ll << 32) &&      // key * row stride stays in the 32-bit per-lane offset
            (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.part_o & 7) == 0;      // 16-byte loads, 8-byte partial stores
 }
 

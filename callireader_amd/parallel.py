@@ -8,6 +8,12 @@ and evenly over ranks (reading order preserved); each rank runs the visual stage
 every rank all pseudo-token embeddings (24 576 B per tile).  Pages are owned round-robin (page p -> rank p % world)
 for the LLM; a page's own tiles (2.1 MB of embeddings each, needed by nobody else) are encoded by its owner.
 `all_gather_rows` is generic: it also carries the 2.1 MB page-tile rows when a caller shards those too.
+
+STRONG scaling (a fixed number of pages per step over more GPUs) has one term that does not divide: the batched decode streams the
+LLM's weights once per step whatever the number of rows (14.7 GB; 3.9 ms at 8 rows, 4.5 ms at 16, 8.9 ms at 64 on MI355X), so eight
+ranks decoding 8 pages each pay for it eight times.  `plan_balanced` therefore lets FEWER ranks own pages (fatter decode batches)
+and hands the other ranks more of the character tiles -- the tile list is still one contiguous partition and there is still ONE
+all-gather, only with uneven shards (`counts`): the split that a cost model of the three stages says finishes first.
 """
 import torch
 import torch.distributed as dist
@@ -24,14 +30,24 @@ def shard_counts(total, world):
     return [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
 
 
-def all_gather_rows(local, total, group=None):
+def _counts(total, world, counts):
+    if counts is None:
+        return shard_counts(total, world)
+    counts = [int(c) for c in counts]
+    if len(counts) != world or sum(counts) != total or min(counts) < 0:
+        raise ValueError(f'shard counts {counts} are not a partition of {total} rows over {world} ranks')
+    return counts
+
+
+def all_gather_rows(local, total, group=None, counts=None):
     """local: (n_local, ...) rows of this rank's contiguous shard of a `total`-row tensor -> (total, ...) on every rank.
-    Ragged shards are padded to the largest one so a single dist.all_gather_into_tensor moves everything."""
+    Ragged shards are padded to the largest one so a single dist.all_gather_into_tensor moves everything.
+    counts: rows per rank when the partition is not the even one (plan_balanced; a rank may have none)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         assert local.shape[0] == total
         return local
-    counts = shard_counts(total, world)
+    counts = _counts(total, world, counts)
     assert local.shape[0] == counts[dist.get_rank(group)], (local.shape, counts)
     mx = max(counts)
     tail = local.shape[1:]
@@ -52,15 +68,15 @@ def all_gather_rows(local, total, group=None):
     return torch.cat([recv[r * mx:r * mx + c] for r, c in enumerate(counts)], dim=0)
 
 
-def all_gather_rows_async(local, total, group=None):
+def all_gather_rows_async(local, total, group=None, counts=None):
     """Start the gather and return `finish() -> (total, ...) tensor`: on RCCL the collective runs on the communicator's
     own stream, so kernels enqueued before finish() (the page tiles' ViT, in bench.py) overlap the transfer over xGMI.
     World size 1 and the gloo host fallback complete immediately."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1 or (local.is_cuda and dist.get_backend(group) == 'gloo'):
-        out = all_gather_rows(local, total, group)
+        out = all_gather_rows(local, total, group, counts)
         return lambda: out
-    counts = shard_counts(total, world)
+    counts = _counts(total, world, counts)
     assert local.shape[0] == counts[dist.get_rank(group)], (local.shape, counts)
     mx = max(counts)
     tail = local.shape[1:]
@@ -81,3 +97,93 @@ def all_gather_rows_async(local, total, group=None):
 
 def owned_pages(n_pages, world, rank):
     return list(range(rank, n_pages, world))
+
+
+# ---- strong scaling: which ranks decode, and how many character tiles each rank encodes ----
+
+# Stage costs on one MI355X at InternVL2-8B shapes, bf16 (profiles/round5: 21_bench_N1_default.json phases, 24_final_decode_rows.txt,
+# 35_decode_rows_9_to_32.txt).  Only the RATIOS matter to the plan; a box that is 3 % slower is 3 % slower at everything.
+MI355X_COST = {
+    'tile_ms': 0.71,                 # one 448 x 448 page tile through ViT + mlp1 ...
+    'char_tile_ms': 0.70,            # ... one character tile through ViT + mlp1 + resampler + VQ + de-norm in long runs (1 711 tiles: 1 195 ms, 36_*)
+    'prefill_ms_per_token': 0.011,   # 34.6 ms per 3 164-token page (splice + prefill + first token of 13 pages: 450 ms)
+    # one decode step of n rows at ~3 200 cached tokens per row (weights 14.7 GB once + 53 MB of KV per row): linear between the points
+    'decode_ms': {1: 2.97, 2: 3.11, 4: 3.30, 8: 3.88, 12: 4.28, 16: 4.58, 24: 5.65, 32: 6.28, 64: 8.86},
+}
+
+
+def decode_step_ms(rows, cost=MI355X_COST):
+    """Piecewise-linear reading of the measured decode table (beyond its last point: the last slope)."""
+    if rows <= 0:
+        return 0.0
+    pts = sorted(cost['decode_ms'].items())
+    if rows <= pts[0][0]:
+        return float(pts[0][1])
+    for (r0, t0), (r1, t1) in zip(pts, pts[1:]):
+        if rows <= r1:
+            return t0 + (t1 - t0) * (rows - r0) / (r1 - r0)
+    (r0, t0), (r1, t1) = pts[-2], pts[-1]
+    return t1 + (t1 - t0) * (rows - r1) / (r1 - r0)
+
+
+def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST, owners=None):
+    """Strong-scaling plan of one step of `n_pages` pages over `world` ranks.
+
+    The first k ranks own the pages (page p -> rank p % k: prefill + decode of its pages, and its pages' own tiles); ALL ranks share the
+    flat list of character tiles in contiguous shards sized so that every rank finishes at the same time (a rank whose pages already fill
+    the step gets none).  k is the one whose slowest rank is fastest under `cost` (or `owners`, when the caller fixes it); k = world with
+    even shards is plan_workload's even split.  Pure host arithmetic, deterministic: every rank computes the same plan.
+
+    Returns {'k', 'pages': [[page ids] per rank], 'char_counts': [per rank], 'char_bounds': [(lo, hi) per rank],
+             'predicted_ms': [per rank], 'predicted_step_ms', 'predicted_even_ms'}."""
+    if n_pages < 1 or world < 1:
+        raise ValueError((n_pages, world))
+    total_ct = n_pages * char_tiles
+    c_tile, c_char = cost['tile_ms'], cost['char_tile_ms']
+
+    def fixed_ms(n_own):
+        if n_own == 0:
+            return 0.0
+        return n_own * (page_tiles * c_tile + prompt_tokens * cost['prefill_ms_per_token']) + (new_tokens - 1) * decode_step_ms(n_own, cost)
+
+    def fill(fixed):
+        """Character tiles per rank: water-filling to a common finishing time, in whole tiles."""
+        lo, hi = 0.0, max(fixed) + total_ct * c_char
+        for _ in range(64):
+            mid = 0.5 * (lo + hi)
+            if sum(max(0.0, (mid - f) / c_char) for f in fixed) >= total_ct:
+                hi = mid
+            else:
+                lo = mid
+        counts = [int(max(0.0, (hi - f) / c_char)) for f in fixed]
+        left = total_ct - sum(counts)
+        while left > 0:                                   # the tiles lost to rounding down: one at a time to the rank that finishes first
+            r = min(range(world), key=lambda i: (fixed[i] + counts[i] * c_char, i))
+            counts[r] += 1
+            left -= 1
+        while left < 0:
+            r = max((i for i in range(world) if counts[i] > 0), key=lambda i: (fixed[i] + counts[i] * c_char, -i))
+            counts[r] -= 1
+            left += 1
+        return counts
+
+    if owners is not None and not 1 <= owners <= min(world, n_pages):
+        raise ValueError(f'{owners} page owners for {n_pages} pages over {world} ranks')
+    best = None
+    for k in ([owners] if owners is not None else range(1, min(world, n_pages) + 1)):
+        own = [len(range(r, n_pages, k)) if r < k else 0 for r in range(world)]
+        fixed = [fixed_ms(n) for n in own]
+        counts = fill(fixed)
+        t = [f + c * c_char for f, c in zip(fixed, counts)]
+        if best is None or max(t) < best['predicted_step_ms'] * (1 - 1e-9):
+            best = {'k': k, 'own': own, 'char_counts': counts, 'predicted_ms': [round(x, 2) for x in t], 'predicted_step_ms': max(t)}
+    k = best['k']
+    even_own = [len(range(r, n_pages, world)) for r in range(world)]
+    even_ct = shard_counts(total_ct, world)
+    bounds, lo = [], 0
+    for c in best['char_counts']:
+        bounds.append((lo, lo + c))
+        lo += c
+    return {'k': k, 'pages': [list(range(r, n_pages, k)) if r < k else [] for r in range(world)], 'char_counts': best['char_counts'], 'char_bounds': bounds,
+            'predicted_ms': best['predicted_ms'], 'predicted_step_ms': round(best['predicted_step_ms'], 2),
+            'predicted_even_ms': round(max(fixed_ms(n) + c * c_char for n, c in zip(even_own, even_ct)), 2)}

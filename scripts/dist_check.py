@@ -12,7 +12,7 @@ import torch.distributed as dist
 from callireader_amd.config import ModelDims
 from callireader_amd import synthetic
 from callireader_amd.modeling_internvl_chat import InternVLChatModel
-from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages
+from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages, plan_balanced
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 backend = os.environ.get('CR_DIST_BACKEND', 'nccl')
@@ -55,6 +55,26 @@ for j, p in enumerate(mine):
     vit_scatter[p * PT:(p + 1) * PT] = vit_own[j * PT:(j + 1) * PT]
 outs_b = dict(zip(mine, run(mine, vit_scatter, pseudo_all)))
 assert outs_b == outs, (outs_b, outs)
+# (c) the balanced strong-scaling plan (parallel.plan_balanced): fewer page owners, uneven character-tile shards (a rank may have none), one gather with
+# explicit counts.  Twice: the cost model's choice, and ONE rank owning every page (the others only encode tiles).
+plans_c = []
+for owners in (None, 1):
+    pl = plan_balanced(n_pages, world, PT, CT, int(ids[0].numel()), NEW, owners=owners)
+    blo, bhi = pl['char_bounds'][rank]
+    if bhi > blo:
+        pc, _ = m.align_tiles(char_px[blo:bhi].cuda())
+    else:
+        pc = torch.empty((0, dims.llm_hidden), dtype=torch.bfloat16, device='cuda')
+    pseudo_c = all_gather_rows(pc.reshape(-1, 3, dims.llm_hidden), n_pages * CT, counts=pl['char_counts'])
+    assert torch.equal(pseudo_c, pseudo_all)
+    mine_c = pl['pages'][rank]
+    outs_c = dict(zip(mine_c, run(mine_c, vit_all, pseudo_c))) if mine_c else {}
+    got_c = [None] * world
+    dist.all_gather_object(got_c, outs_c)
+    merged_c = {}
+    for g in got_c:
+        merged_c.update(g)
+    plans_c.append((pl, merged_c))
 gathered = [None] * world
 dist.all_gather_object(gathered, outs)
 if rank == 0:
@@ -65,6 +85,8 @@ if rank == 0:
     p1, _ = m.align_tiles(char_px.cuda())
     single = run(list(range(n_pages)), v1, p1.reshape(-1, 3, dims.llm_hidden))
     ok = all(merged[p] == single[p] for p in range(n_pages)) and torch.equal(v1, vit_all)
+    ok = ok and all(sorted(mc) == list(range(n_pages)) and all(mc[p] == single[p] for p in range(n_pages)) for _, mc in plans_c)
+    ok = ok and plans_c[1][0]['k'] == 1
     print('DIST_CHECK', 'OK' if ok else 'MISMATCH', merged, single, flush=True)
     out = os.environ.get('CR_DIST_JSON')
     if out:
@@ -75,6 +97,7 @@ if rank == 0:
                    'world_size': world, 'backend': backend, 'visible_gpus': torch.cuda.device_count(), 'pages': n_pages,
                    'pages_per_rank': [len(owned_pages(n_pages, world, r)) for r in range(world)],
                    'char_tile_shards': shard_counts(n_pages * CT, world), 'page_tile_shards': shard_counts(n_pages * PT, world),
+                   'balanced_plans': [{'page_owners': pl['k'], 'pages_per_rank': [len(x) for x in pl['pages']], 'char_tiles_per_rank': pl['char_counts']} for pl, _ in plans_c],
                    'ids_equal_single_process': bool(ok), 'ids': {str(k): v for k, v in sorted(merged.items())}}, open(out, 'w'), indent=1)
 dist.barrier()
 dist.destroy_process_group()

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from callireader_amd.parallel import shard_range, shard_counts, all_gather_rows, all_gather_rows_async, owned_pages
+from callireader_amd.parallel import shard_range, shard_counts, all_gather_rows, all_gather_rows_async, owned_pages, plan_balanced, decode_step_ms, MI355X_COST
 
 
 def test_shard_range_is_an_even_contiguous_partition():
@@ -65,6 +65,86 @@ def test_all_gather_rows_gloo(world, total):
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
     assert all(r[2] == (total, 3, 4) for r in res)
+
+
+def _worker_counts(rank, world, port, counts, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        total = sum(counts)
+        full = torch.arange(total * 3 * 4, dtype=torch.float32).reshape(total, 3, 4).to(torch.bfloat16)
+        lo = sum(counts[:rank])
+        mine = full[lo:lo + counts[rank]].clone()
+        ok = torch.equal(all_gather_rows(mine, total, counts=counts), full)
+        ok = ok and torch.equal(all_gather_rows_async(mine, total, counts=counts)(), full)
+        bad = False
+        try:
+            all_gather_rows(mine, total, counts=counts[:-1] + [counts[-1] + 1])       # not a partition of `total`: refused before anything is sent
+        except ValueError:
+            bad = True
+        q.put((rank, bool(ok and bad)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('counts', [[5, 3], [0, 7], [2, 0, 9], [194, 194, 194, 194, 265, 1701, 1701, 1701]])
+def test_all_gather_rows_uneven_counts_gloo(counts):
+    """The balanced strong-scaling plan's gather: explicit rows per rank, uneven, a rank may have none; the last case is the 64-pages-over-8 plan's shards."""
+    world = len(counts)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_counts, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] for r in res), res
+
+
+def test_plan_balanced_is_a_partition_and_never_worse_than_the_even_split():
+    """parallel.plan_balanced (strong scaling): every page has one owner among the first k ranks, the character tiles are one contiguous partition, the plan is
+    deterministic, and its predicted step is never slower than the even split's under the same cost model (k = world is among the candidates)."""
+    assert decode_step_ms(8) == MI355X_COST['decode_ms'][8] and decode_step_ms(0) == 0.0
+    assert MI355X_COST['decode_ms'][8] < decode_step_ms(12) < MI355X_COST['decode_ms'][16] and decode_step_ms(128) > decode_step_ms(64)
+    for n_pages, world in [(64, 1), (64, 2), (64, 4), (64, 8), (11, 8), (3, 8), (1, 4), (100, 7)]:
+        pl = plan_balanced(n_pages, world, 11, 96, 3164, 128)
+        assert pl == plan_balanced(n_pages, world, 11, 96, 3164, 128)
+        k = pl['k']
+        assert 1 <= k <= min(world, n_pages)
+        assert sorted(p for r in pl['pages'] for p in r) == list(range(n_pages))
+        assert all(pl['pages'][r] == list(range(r, n_pages, k)) for r in range(k)) and all(pl['pages'][r] == [] for r in range(k, world))
+        assert sum(pl['char_counts']) == n_pages * 96 and min(pl['char_counts']) >= 0
+        assert pl['char_bounds'][0][0] == 0 and pl['char_bounds'][-1][1] == n_pages * 96
+        assert all(pl['char_bounds'][i][1] == pl['char_bounds'][i + 1][0] for i in range(world - 1))
+        assert [b - a for a, b in pl['char_bounds']] == pl['char_counts']
+        assert pl['predicted_step_ms'] <= pl['predicted_even_ms'] + 1.0
+        assert abs(max(pl['predicted_ms']) - pl['predicted_step_ms']) < 0.01
+    # BASELINE config 4 (64 pages over 8 MI355X): the decode's weight stream is paid by 5 ranks instead of 8, and the plan says >= 8 % off the step
+    pl = plan_balanced(64, 8, 11, 96, 3164, 128)
+    assert pl['k'] < 8 and pl['predicted_step_ms'] < 0.92 * pl['predicted_even_ms']
+    assert max(pl['predicted_ms']) - min(pl['predicted_ms']) < 2.0                      # every rank finishes within two tiles of the others
+    # a cost model in which decode steps are free keeps every rank decoding (fewer owners only add prefill + page tiles per owner)
+    free = dict(MI355X_COST, decode_ms={1: 0.0, 64: 0.0})
+    assert plan_balanced(64, 8, 11, 96, 3164, 128, cost=free)['k'] == 8
+    one = plan_balanced(3, 2, 2, 5, 540, 6, owners=1)                                     # the caller fixes the number of owners (scripts/dist_check.py)
+    assert one['k'] == 1 and one['pages'] == [[0, 1, 2], []] and sum(one['char_counts']) == 15
+    with pytest.raises(ValueError):
+        plan_balanced(3, 2, 2, 5, 540, 6, owners=3)
+
+
+def test_bench_balanced_plan_matches_the_planner():
+    import bench
+    plans = [bench.plan_workload('strong', 64, 64, 8, r, plan='balanced') for r in range(8)]
+    pb = plans[0]['balanced']
+    assert all(w['balanced'] == pb and w['ct_counts'] == pb['char_counts'] for w in plans)
+    assert [w['mine'] for w in plans] == pb['pages'] and [(w['ct_lo'], w['ct_hi']) for w in plans] == pb['char_bounds']
+    assert [w['pages_per_gpu'] for w in plans] == [len(x) for x in pb['pages']]
+    with pytest.raises(ValueError):
+        bench.plan_workload('weak', 64, 64, 8, 0, plan='balanced')
 
 
 def test_single_process_passthrough():
