@@ -126,25 +126,44 @@ def decode_step_ms(rows, cost=MI355X_COST):
     return t1 + (t1 - t0) * (rows - r1) / (r1 - r0)
 
 
+def _per_page(x, n, what):
+    if isinstance(x, int):
+        return [x] * n
+    x = [int(v) for v in x]
+    if len(x) != n or (x and min(x) < 0):
+        raise ValueError(f'{what}: {len(x)} entries for {n} pages')
+    return x
+
+
 def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST, owners=None):
-    """Strong-scaling plan of one step of `n_pages` pages over `world` ranks.
+    """Strong-scaling plan of one step of `n_pages` pages over `world` ranks.  page_tiles / char_tiles / prompt_tokens: one number for every
+    page, or one per page (real pages differ in their character count and prompt length).
 
-    The first k ranks own the pages (page p -> rank p % k: prefill + decode of its pages, and its pages' own tiles); ALL ranks share the
-    flat list of character tiles in contiguous shards sized so that every rank finishes at the same time (a rank whose pages already fill
-    the step gets none).  k is the one whose slowest rank is fastest under `cost` (or `owners`, when the caller fixes it); k = world with
-    even shards is plan_workload's even split.  Pure host arithmetic, deterministic: every rank computes the same plan.
+    The first k ranks own the pages (prefill + decode of their pages, and their pages' own tiles): pages go, dearest first, to the owner
+    with the least work so far -- page p -> rank p % k when all pages are alike; ALL ranks share the flat list of character tiles (page
+    order) in contiguous shards sized so that every rank finishes at the same time (a rank whose pages already fill the step gets none).
+    k is the one whose slowest rank is fastest under `cost` (or `owners`, when the caller fixes it); k = world with even shards is the
+    even split.  Pure host arithmetic, deterministic: every rank computes the same plan.
 
-    Returns {'k', 'pages': [[page ids] per rank], 'char_counts': [per rank], 'char_bounds': [(lo, hi) per rank],
-             'predicted_ms': [per rank], 'predicted_step_ms', 'predicted_even_ms'}."""
+    Returns {'k', 'pages': [[page ids] per rank], 'owner': [rank per page], 'char_counts': [per rank], 'char_bounds': [(lo, hi) per rank],
+             'char_offsets': [first flat index per page] + [total], 'predicted_ms': [per rank], 'predicted_step_ms', 'predicted_even_ms'}."""
     if n_pages < 1 or world < 1:
         raise ValueError((n_pages, world))
-    total_ct = n_pages * char_tiles
+    pt, ct, tok = _per_page(page_tiles, n_pages, 'page_tiles'), _per_page(char_tiles, n_pages, 'char_tiles'), _per_page(prompt_tokens, n_pages, 'prompt_tokens')
+    total_ct = sum(ct)
     c_tile, c_char = cost['tile_ms'], cost['char_tile_ms']
+    page_ms = [pt[p] * c_tile + tok[p] * cost['prefill_ms_per_token'] for p in range(n_pages)]
+    by_cost = sorted(range(n_pages), key=lambda p: (-page_ms[p], p))
 
-    def fixed_ms(n_own):
-        if n_own == 0:
-            return 0.0
-        return n_own * (page_tiles * c_tile + prompt_tokens * cost['prefill_ms_per_token']) + (new_tokens - 1) * decode_step_ms(n_own, cost)
+    def assign(k):
+        load, pages = [0.0] * k, [[] for _ in range(k)]
+        for p in by_cost:
+            r = min(range(k), key=lambda i: (load[i], i))
+            load[r] += page_ms[p]
+            pages[r].append(p)
+        pages = [sorted(x) for x in pages] + [[] for _ in range(world - k)]
+        fixed = [sum(page_ms[p] for p in x) + ((new_tokens - 1) * decode_step_ms(len(x), cost) if x else 0.0) for x in pages]
+        return pages, fixed
 
     def fill(fixed):
         """Character tiles per rank: water-filling to a common finishing time, in whole tiles."""
@@ -171,19 +190,85 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
         raise ValueError(f'{owners} page owners for {n_pages} pages over {world} ranks')
     best = None
     for k in ([owners] if owners is not None else range(1, min(world, n_pages) + 1)):
-        own = [len(range(r, n_pages, k)) if r < k else 0 for r in range(world)]
-        fixed = [fixed_ms(n) for n in own]
+        pages, fixed = assign(k)
         counts = fill(fixed)
         t = [f + c * c_char for f, c in zip(fixed, counts)]
         if best is None or max(t) < best['predicted_step_ms'] * (1 - 1e-9):
-            best = {'k': k, 'own': own, 'char_counts': counts, 'predicted_ms': [round(x, 2) for x in t], 'predicted_step_ms': max(t)}
-    k = best['k']
-    even_own = [len(range(r, n_pages, world)) for r in range(world)]
+            best = {'k': k, 'pages': pages, 'char_counts': counts, 'predicted_ms': [round(x, 2) for x in t], 'predicted_step_ms': max(t)}
+    even_fixed = assign(min(world, n_pages))[1]
     even_ct = shard_counts(total_ct, world)
     bounds, lo = [], 0
     for c in best['char_counts']:
         bounds.append((lo, lo + c))
         lo += c
-    return {'k': k, 'pages': [list(range(r, n_pages, k)) if r < k else [] for r in range(world)], 'char_counts': best['char_counts'], 'char_bounds': bounds,
+    offsets = [0]
+    for c in ct:
+        offsets.append(offsets[-1] + c)
+    owner = [0] * n_pages
+    for r, x in enumerate(best['pages']):
+        for p in x:
+            owner[p] = r
+    return {'k': best['k'], 'pages': best['pages'], 'owner': owner, 'char_counts': best['char_counts'], 'char_bounds': bounds, 'char_offsets': offsets,
             'predicted_ms': best['predicted_ms'], 'predicted_step_ms': round(best['predicted_step_ms'], 2),
-            'predicted_even_ms': round(max(fixed_ms(n) + c * c_char for n, c in zip(even_own, even_ct)), 2)}
+            'predicted_even_ms': round(max(f + c * c_char for f, c in zip(even_fixed, even_ct)), 2)}
+
+
+def sharded_generate(model, page_tiles, char_tiles, input_ids, *, img_id, ref_id, max_new_tokens, plan=None, group=None, gather_results=True, **generate_kw):
+    """One step of a batch of pages over the ranks of `group`: the multi-GPU form of `model.generate_pages` (the reference has none: inference.py:47-59
+    is a serial page loop).  Every rank calls it with the SAME host-side lists --
+
+        page_tiles[p]  (n_p, 3, 448, 448) the page's own tiles        char_tiles[p]  (c_p, 3, 448, 448) its character tiles, reading order
+        input_ids[p]   the page's prompt ids (n_p * 256 `img_id` + c_p * 3 `ref_id` placeholders)
+
+    -- and encodes only its share: its contiguous shard of the flat character-tile list (ViT -> mlp1 -> resampler -> VQ -> de-norm), ONE all-gather of the
+    24.5 KB pseudo-token rows, then, for the pages it owns, their own tiles (ViT -> mlp1, under the gather), the splice, prefill and greedy decode.
+    plan: a `plan_balanced` result (default: computed here from the lists' sizes -- fewer, fatter decode batches); `plan_even(...)` for one page owner per rank.
+    Returns {page: ids} for every page (gather_results) or for the pages this rank owns.  Per page the ids are the single-process ids."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_pages = len(input_ids)
+    if len(page_tiles) != n_pages or len(char_tiles) != n_pages:
+        raise ValueError('page_tiles, char_tiles and input_ids are one entry per page')
+    if plan is None:
+        plan = plan_balanced(n_pages, world, [int(t.shape[0]) for t in page_tiles], [int(t.shape[0]) for t in char_tiles], [int(i.numel()) for i in input_ids], max_new_tokens)
+    if len(plan['char_counts']) != world or plan['char_offsets'][-1] != sum(int(t.shape[0]) for t in char_tiles):
+        raise ValueError('the plan was made for another world size or another batch')
+    dev = model.engine.device
+    hidden = model.engine.dims.llm_hidden
+    lo, hi = plan['char_bounds'][rank]
+    off = plan['char_offsets']
+    if hi > lo:                                          # the pieces of the flat list [lo, hi), page by page
+        parts = [char_tiles[p][max(lo, off[p]) - off[p]:min(hi, off[p + 1]) - off[p]] for p in range(n_pages) if off[p] < hi and off[p + 1] > lo]
+        pseudo, _ = model.align_tiles(torch.cat(parts).to(dev))
+        pseudo = pseudo.reshape(-1, 3, hidden)
+    else:
+        pseudo = torch.empty((0, 3, hidden), dtype=torch.bfloat16, device=dev)
+    finish = all_gather_rows_async(pseudo, off[-1], group, counts=plan['char_counts'])
+    mine = plan['pages'][rank]
+    vit = {}
+    for p in mine:                                       # (pages without tiles of their own exist: c_p only)
+        vit[p] = model.extract_feature(page_tiles[p].to(dev)) if page_tiles[p].shape[0] else None
+    pseudo_all = finish()
+    embeds = [model.engine.embed_splice(input_ids[p].to(dev), vit[p], pseudo_all[off[p]:off[p + 1]] if off[p + 1] > off[p] else None, img_id=img_id, ref_id=ref_id)
+              for p in mine]
+    outs = model.generate_pages(embeds, max_new_tokens=max_new_tokens, **generate_kw) if embeds else []
+    result = dict(zip(mine, outs))
+    if gather_results and world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, result, group=group)
+        result = {}
+        for g in got:
+            result.update(g)
+    return result
+
+
+def plan_even(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST):
+    """The even split in plan_balanced's format: page p -> rank p % world, character tiles in even contiguous shards."""
+    pl = plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=cost, owners=min(world, n_pages))
+    k = min(world, n_pages)
+    pl['pages'] = [list(range(r, n_pages, k)) if r < k else [] for r in range(world)]
+    pl['owner'] = [p % k for p in range(n_pages)]
+    pl['char_counts'] = shard_counts(pl['char_offsets'][-1], world)
+    pl['char_bounds'] = [shard_range(pl['char_offsets'][-1], world, r) for r in range(world)]
+    pl['predicted_ms'], pl['predicted_step_ms'] = None, pl['predicted_even_ms']
+    return pl

@@ -12,7 +12,7 @@ import torch.distributed as dist
 from callireader_amd.config import ModelDims
 from callireader_amd import synthetic
 from callireader_amd.modeling_internvl_chat import InternVLChatModel
-from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages, plan_balanced
+from callireader_amd.parallel import shard_range, all_gather_rows, owned_pages, plan_balanced, plan_even, sharded_generate
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 backend = os.environ.get('CR_DIST_BACKEND', 'nccl')
@@ -55,26 +55,20 @@ for j, p in enumerate(mine):
     vit_scatter[p * PT:(p + 1) * PT] = vit_own[j * PT:(j + 1) * PT]
 outs_b = dict(zip(mine, run(mine, vit_scatter, pseudo_all)))
 assert outs_b == outs, (outs_b, outs)
-# (c) the balanced strong-scaling plan (parallel.plan_balanced): fewer page owners, uneven character-tile shards (a rank may have none), one gather with
-# explicit counts.  Twice: the cost model's choice, and ONE rank owning every page (the others only encode tiles).
+# (c) parallel.sharded_generate, the library form of flow (b), under three plans: the cost model's (fewer page owners, uneven character-tile shards: a rank
+# may own no page or encode no tile), ONE rank owning every page, the even split.  Then RAGGED pages (1..CT character tiles, a page without tiles of its own).
+sizes = ([PT] * n_pages, [CT] * n_pages, [int(i.numel()) for i in ids])
+pages_pt = [page_px[p * PT:(p + 1) * PT] for p in range(n_pages)]
+pages_ct = [char_px[p * CT:(p + 1) * CT] for p in range(n_pages)]
 plans_c = []
-for owners in (None, 1):
-    pl = plan_balanced(n_pages, world, PT, CT, int(ids[0].numel()), NEW, owners=owners)
-    blo, bhi = pl['char_bounds'][rank]
-    if bhi > blo:
-        pc, _ = m.align_tiles(char_px[blo:bhi].cuda())
-    else:
-        pc = torch.empty((0, dims.llm_hidden), dtype=torch.bfloat16, device='cuda')
-    pseudo_c = all_gather_rows(pc.reshape(-1, 3, dims.llm_hidden), n_pages * CT, counts=pl['char_counts'])
-    assert torch.equal(pseudo_c, pseudo_all)
-    mine_c = pl['pages'][rank]
-    outs_c = dict(zip(mine_c, run(mine_c, vit_all, pseudo_c))) if mine_c else {}
-    got_c = [None] * world
-    dist.all_gather_object(got_c, outs_c)
-    merged_c = {}
-    for g in got_c:
-        merged_c.update(g)
-    plans_c.append((pl, merged_c))
+for pl in (plan_balanced(n_pages, world, *sizes, NEW), plan_balanced(n_pages, world, *sizes, NEW, owners=1), plan_even(n_pages, world, *sizes, NEW)):
+    plans_c.append((pl, sharded_generate(m, pages_pt, pages_ct, ids, img_id=IMG, ref_id=REF, max_new_tokens=NEW, eos_token_id=None, plan=pl)))
+rag_ct = [1 + (3 * p) % CT for p in range(n_pages)]
+rag_pt = [0 if p == 1 else PT for p in range(n_pages)]
+rag_pages_pt = [page_px[p * PT:p * PT + rag_pt[p]] for p in range(n_pages)]
+rag_pages_ct = [char_px[p * CT:p * CT + rag_ct[p]] for p in range(n_pages)]
+rag_ids = [torch.cat([torch.arange(50 + p, 60 + p), torch.full((rag_pt[p] * 256,), IMG), torch.full((rag_ct[p] * 3,), REF), torch.arange(7)]) for p in range(n_pages)]
+rag_out = sharded_generate(m, rag_pages_pt, rag_pages_ct, rag_ids, img_id=IMG, ref_id=REF, max_new_tokens=NEW, eos_token_id=None)
 gathered = [None] * world
 dist.all_gather_object(gathered, outs)
 if rank == 0:
@@ -87,6 +81,13 @@ if rank == 0:
     ok = all(merged[p] == single[p] for p in range(n_pages)) and torch.equal(v1, vit_all)
     ok = ok and all(sorted(mc) == list(range(n_pages)) and all(mc[p] == single[p] for p in range(n_pages)) for _, mc in plans_c)
     ok = ok and plans_c[1][0]['k'] == 1
+    rag_embeds = []
+    for p in range(n_pages):
+        v = m.extract_feature(rag_pages_pt[p].cuda()) if rag_pt[p] else None
+        ps, _ = m.align_tiles(rag_pages_ct[p].cuda())                      # page by page: a tile's rows do not depend on its batch
+        rag_embeds.append(m.engine.embed_splice(rag_ids[p].cuda(), v, ps.reshape(-1, 3, dims.llm_hidden), img_id=IMG, ref_id=REF))
+    rag_single = m.generate_pages(rag_embeds, max_new_tokens=NEW, eos_token_id=None)
+    ok = ok and sorted(rag_out) == list(range(n_pages)) and all(rag_out[p] == rag_single[p] for p in range(n_pages))
     print('DIST_CHECK', 'OK' if ok else 'MISMATCH', merged, single, flush=True)
     out = os.environ.get('CR_DIST_JSON')
     if out:
@@ -97,7 +98,8 @@ if rank == 0:
                    'world_size': world, 'backend': backend, 'visible_gpus': torch.cuda.device_count(), 'pages': n_pages,
                    'pages_per_rank': [len(owned_pages(n_pages, world, r)) for r in range(world)],
                    'char_tile_shards': shard_counts(n_pages * CT, world), 'page_tile_shards': shard_counts(n_pages * PT, world),
-                   'balanced_plans': [{'page_owners': pl['k'], 'pages_per_rank': [len(x) for x in pl['pages']], 'char_tiles_per_rank': pl['char_counts']} for pl, _ in plans_c],
+                   'sharded_generate_plans': [{'page_owners': pl['k'], 'pages_per_rank': [len(x) for x in pl['pages']], 'char_tiles_per_rank': pl['char_counts']} for pl, _ in plans_c],
+                   'ragged_pages': {'char_tiles_per_page': rag_ct, 'page_tiles_per_page': rag_pt},
                    'ids_equal_single_process': bool(ok), 'ids': {str(k): v for k, v in sorted(merged.items())}}, open(out, 'w'), indent=1)
 dist.barrier()
 dist.destroy_process_group()

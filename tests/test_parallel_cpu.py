@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from callireader_amd.parallel import shard_range, shard_counts, all_gather_rows, all_gather_rows_async, owned_pages, plan_balanced, decode_step_ms, MI355X_COST
+from callireader_amd.parallel import (shard_range, shard_counts, all_gather_rows, all_gather_rows_async, owned_pages, plan_balanced, plan_even, sharded_generate,
+                                     decode_step_ms, MI355X_COST)
 
 
 def test_shard_range_is_an_even_contiguous_partition():
@@ -145,6 +146,109 @@ def test_bench_balanced_plan_matches_the_planner():
     assert [w['pages_per_gpu'] for w in plans] == [len(x) for x in pb['pages']]
     with pytest.raises(ValueError):
         bench.plan_workload('weak', 64, 64, 8, 0, plan='balanced')
+
+
+class _StubModel:
+    """Stands in for InternVLChatModel in the CPU test of sharded_generate: every stage is a pure per-tile / per-page function (as the HIP stages are:
+    a tile's rows do not depend on its batch), cheap enough for gloo workers."""
+    class _Eng:
+        device = torch.device('cpu')
+
+        class dims:
+            llm_hidden = 8
+
+        @staticmethod
+        def embed_splice(ids, vit, pseudo, img_id, ref_id):
+            vit = torch.zeros(0, 256, 8) if vit is None else vit              # (a page without tiles of its own / without characters hands None)
+            pseudo = torch.zeros(0, 3, 8) if pseudo is None else pseudo
+            assert int((ids == img_id).sum()) == vit.shape[0] * 256 and int((ids == ref_id).sum()) == pseudo.shape[0] * 3
+            return (ids.clone(), vit.float().sum(dim=(1, 2)), pseudo.float().sum(dim=(1, 2)))
+    engine = _Eng()
+
+    @staticmethod
+    def _tile_value(px):
+        return px.float().sum(dim=(1, 2, 3))
+
+    def align_tiles(self, px):
+        v = self._tile_value(px)
+        rows = torch.stack([v, v + 1, v + 2], dim=1).reshape(-1, 1).expand(-1, 8)
+        return rows.to(torch.bfloat16).contiguous(), None
+
+    def extract_feature(self, px):
+        return self._tile_value(px).reshape(-1, 1, 1).expand(-1, 256, 8).to(torch.bfloat16).contiguous()
+
+    def generate_pages(self, embeds, max_new_tokens, **kw):
+        return [[int(ids.sum()) % 9973, int(v.sum()) % 9973, int(ps.sum()) % 9973, len(embeds) * 0 + max_new_tokens] for ids, v, ps in embeds]
+
+
+def _stub_batch():
+    IMG, REF = 901, 902
+    g = torch.Generator().manual_seed(3)
+    pts, cts = [2, 0, 1, 2, 1], [5, 1, 9, 0, 4]                      # ragged: a page without tiles of its own, a page without characters
+    page_tiles = [torch.randint(0, 7, (n, 3, 4, 4), generator=g).float() for n in pts]
+    char_tiles = [torch.randint(0, 7, (n, 3, 4, 4), generator=g).float() for n in cts]
+    ids = [torch.cat([torch.arange(10 + p, 14 + p), torch.full((pts[p] * 256,), IMG), torch.full((cts[p] * 3,), REF), torch.arange(3)]) for p in range(5)]
+    return page_tiles, char_tiles, ids, IMG, REF
+
+
+def _worker_sharded(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        page_tiles, char_tiles, ids, IMG, REF = _stub_batch()
+        m = _StubModel()
+        sizes = ([t.shape[0] for t in page_tiles], [t.shape[0] for t in char_tiles], [i.numel() for i in ids])
+        outs = []
+        for plan in (None, plan_balanced(5, world, *sizes, 16, owners=1), plan_even(5, world, *sizes, 16)):
+            outs.append(sharded_generate(m, page_tiles, char_tiles, ids, img_id=IMG, ref_id=REF, max_new_tokens=16, plan=plan))
+        own = sharded_generate(m, page_tiles, char_tiles, ids, img_id=IMG, ref_id=REF, max_new_tokens=16, gather_results=False)
+        q.put((rank, outs, sorted(own)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_generate_equals_single_process_gloo(world):
+    """parallel.sharded_generate (the multi-GPU form of generate_pages) on a stub model, ragged pages, three plans (the cost model's, one page owner, the even
+    split): every page's result is the single-process result, whichever rank encoded its tiles and whichever rank owned it."""
+    page_tiles, char_tiles, ids, IMG, REF = _stub_batch()
+    m = _StubModel()
+    pseudo, _ = m.align_tiles(torch.cat(char_tiles))
+    pseudo = pseudo.reshape(-1, 3, 8)
+    off = [0]
+    for t in char_tiles:
+        off.append(off[-1] + t.shape[0])
+    embeds = [m.engine.embed_splice(ids[p], m.extract_feature(page_tiles[p]) if page_tiles[p].shape[0] else None, pseudo[off[p]:off[p + 1]], IMG, REF) for p in range(5)]
+    single = dict(enumerate(m.generate_pages(embeds, 16)))
+    assert sharded_generate(m, page_tiles, char_tiles, ids, img_id=IMG, ref_id=REF, max_new_tokens=16) == single       # no process group: one rank
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, own in res:
+        assert all(o == single for o in outs), (rank, outs, single)
+    assert sorted(p for _, _, own in res for p in own) == list(range(5))                 # gather_results=False: every page exactly once over the ranks
+
+
+def test_plan_balanced_ragged_pages():
+    """Per-page sizes: dearest pages first to the least-loaded owner; the character-tile shards still partition the flat list; alike pages reproduce p % k."""
+    ct = [5, 200, 17, 96, 96, 3, 150, 42, 96, 10, 77]
+    tok = [60 + 11 * 256 + 3 * c for c in ct]
+    pl = plan_balanced(11, 8, 11, ct, tok, 128)
+    assert sorted(p for r in pl['pages'] for p in r) == list(range(11)) and all(pl['owner'][p] == r for r, x in enumerate(pl['pages']) for p in x)
+    assert sum(pl['char_counts']) == sum(ct) == pl['char_offsets'][-1] and pl['char_offsets'][3] == 5 + 200 + 17
+    assert pl['predicted_step_ms'] <= pl['predicted_even_ms'] + 1.0
+    with pytest.raises(ValueError):
+        plan_balanced(11, 8, 11, ct[:-1], tok, 128)
+    ev = plan_even(11, 8, 11, ct, tok, 128)
+    assert ev['pages'] == [[r, r + 8] if r + 8 < 11 else [r] for r in range(8)] and ev['char_counts'] == shard_counts(sum(ct), 8)
 
 
 def test_single_process_passthrough():
