@@ -289,6 +289,7 @@ def main():
     ap.add_argument('--no-strong-block', action='store_true',
                     help='N > 1 with weak scaling: do not append the strong-scaling block (BASELINE config 4 as written: --total-pages per step over all ranks) to the line')
     ap.add_argument('--strong-steps', type=int, default=2, help='timed steps of that block')
+    ap.add_argument('--no-balanced', action='store_true', help='do not run the balanced strong-scaling plan (strong_scaling.balanced at N > 1, strong_share.balanced at N = 1)')
     ap.add_argument('--no-strong-share', action='store_true', help='N = 1: do not time one rank\'s share of the strong-scaling step (strong_share)')
     ap.add_argument('--share-world', type=int, default=8, help='the world size whose rank-0 share strong_share runs on this one GPU')
     ap.add_argument('--share-steps', type=int, default=2, help='timed steps of strong_share')
@@ -567,7 +568,7 @@ def main():
         balanced = None
         wb0 = plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced')
         pb = wb0['balanced']
-        if pb['k'] < args.share_world:
+        if pb['k'] < args.share_world and not args.no_balanced:
             ra = max(range(args.share_world), key=lambda r: (len(pb['pages'][r]), pb['char_counts'][r], -r))
             rb = max(range(args.share_world), key=lambda r: (pb['char_counts'][r], -r))
             nA, cA, cB = len(pb['pages'][ra]), pb['char_counts'][ra], pb['char_counts'][rb]
@@ -672,7 +673,7 @@ def main():
         # ... and under the balanced plan (parallel.plan_balanced: fewer page owners, uneven character-tile shards, the same one all-gather)
         bal = None
         wbal = plan_workload('strong', args.pages, args.total_pages, world, rank, plan='balanced')
-        if wbal['balanced']['k'] < world and max(len(x) for x in wbal['balanced']['pages']) <= P:
+        if wbal['balanced']['k'] < world and max(len(x) for x in wbal['balanced']['pages']) <= P and not args.no_balanced:
             ins_b = make_inputs(wbal)
             step(w=wbal, inputs=ins_b)
             sync()

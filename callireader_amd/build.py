@@ -2,7 +2,6 @@
 
 The library carries the hash of the sources it was compiled from (`cr_build_id()`, include/callireader_hip.h): a build is
 stale when that hash differs from the sources on disk -- file times do not survive a copy to another box, contents do."""
-import ctypes
 import hashlib
 import os
 import shutil

@@ -1,5 +1,4 @@
 """CalliAlign parity on a real MI355X: resampler, cosine VQ, de-normalisation vs the CPU oracle."""
-import math
 
 import pytest
 import torch
