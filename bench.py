@@ -68,7 +68,7 @@ def build_ids(n_page_tiles, n_char_tiles, text_tokens, img_id, ref_id, seed):
     return torch.cat([head, torch.full((n_page_tiles * 256,), img_id), torch.full((n_char_tiles * 3,), ref_id), tail])
 
 
-def plan_workload(scaling, pages, total_pages, world, rank, plan='even'):
+def plan_workload(scaling, pages, total_pages, world, rank, plan='even', cost=None):
     """Which pages and which character tiles one rank handles in a step.  weak: `pages` per GPU whatever N (n_pages = pages * world);
     strong: `total_pages` per step over all ranks (BASELINE config 4 as written: 64 pages over 8 GPUs).  plan 'even': pages are owned
     round-robin, the flat list of character tiles is split contiguously and evenly; plan 'balanced' (strong only): fewer ranks own pages
@@ -80,7 +80,8 @@ def plan_workload(scaling, pages, total_pages, world, rank, plan='even'):
     if plan == 'balanced':
         if scaling != 'strong':
             raise ValueError('the balanced plan is a strong-scaling plan')
-        pb = plan_balanced(n_pages, world, PAGE_TILES, CHAR_TILES, PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS, NEW_TOKENS)
+        from callireader_amd.parallel import MI355X_COST
+        pb = plan_balanced(n_pages, world, PAGE_TILES, CHAR_TILES, PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS, NEW_TOKENS, cost=cost or MI355X_COST)
         lo, hi = pb['char_bounds'][rank]
         return {'scaling': scaling, 'plan': 'balanced', 'n_pages': n_pages, 'mine': pb['pages'][rank], 'ct_lo': lo, 'ct_hi': hi, 'ct_counts': pb['char_counts'],
                 'pages_per_gpu': len(pb['pages'][rank]), 'balanced': pb}
@@ -515,6 +516,57 @@ def main():
                    'tflops': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12, 1),
                    'mfma_frac': round((vis_fl + pre_fl) / (st[2] - st[0]) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
+    def measure_balanced(pb, full_ms, full_out, pipelined_ms, n_even, cost_name='MI355X_COST'):
+        """strong_share.balanced: the two kinds of rank of a plan_balanced plan, each timed alone on this GPU against the one-GPU step `full_ms` (whose ids are `full_out`)."""
+        sw = args.share_world
+        if pb['k'] >= sw:
+            return None
+        ra = max(range(sw), key=lambda r: (len(pb['pages'][r]), pb['char_counts'][r], -r))
+        rb = max(range(sw), key=lambda r: (pb['char_counts'][r], -r))
+        nA, cA, cB = len(pb['pages'][ra]), pb['char_counts'][ra], pb['char_counts'][rb]
+
+        def timed_share(w, ins_):
+            step(w=w, inputs=ins_)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            out_ = None
+            for _ in range(args.share_steps):
+                out_ = step(w=w, inputs=ins_)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / args.share_steps * 1e3, out_
+        pseudo_a, _ = model.align_tiles(char_px[:nA * CHAR_TILES])                       # what the gather hands rank A for its pages
+        w_a = {'n_pages': nA, 'mine': list(range(nA)), 'pseudo_all': pseudo_a.reshape(-1, 3, dims.llm_hidden)}
+        ins_a = (page_px[:nA * PAGE_TILES], char_px[:cA], ids[:nA])
+        t_a, out_a = timed_share(w_a, ins_a)
+        st4 = [0.0]
+        torch.cuda.synchronize(); st4[0] = time.perf_counter()
+        step(new_tokens=1, stamps=st4, w=w_a, inputs=ins_a)
+        same_a = bool(out_a == full_out[:nA])
+        del pseudo_a, w_a, ins_a
+        t_b = None
+        if not pb['pages'][rb]:
+            w_b = {'n_pages': 0, 'mine': [], 'pseudo_all': torch.empty((0, 3, dims.llm_hidden), dtype=torch.bfloat16, device=dev)}
+            t_b, _ = timed_share(w_b, (page_px[:0], char_px[:cB], []))
+        t_bal = max(t_a, t_b or 0.0)
+        return {
+            'what': f'the same {args.pages} pages over {sw} GPUs under parallel.plan_balanced: {pb["k"]} ranks own the pages ({nA} rows per decode batch instead of {n_even}; '
+                    'the decode streams the weights once per step whatever the rows), all ranks share the character tiles in uneven contiguous shards, still ONE all-gather; '
+                    'the two kinds of rank timed alone on this GPU, one batch at a time',
+            'plan': {'page_owners': pb['k'], 'pages_per_rank': [len(x) for x in pb['pages']], 'char_tiles_per_rank': pb['char_counts'],
+                     'predicted_ms_per_rank': pb['predicted_ms'], 'predicted_even_plan_ms': pb['predicted_even_ms'],
+                     'cost_model': f'callireader_amd/parallel.py: {cost_name} (ms per tile, per prompt token, per decode step by rows), measured in profiles/round5'},
+            'page_owner_rank': {'rank': ra, 'pages_owned': nA, 'char_tiles': cA, 't_ms': round(t_a, 2),
+                                'phases_ms': {'visual': round((st4[1] - st4[0]) * 1e3, 1), 'splice_prefill_first_token': round((st4[2] - st4[1]) * 1e3, 1),
+                                              'decode_remaining_tokens': round(max(t_a - (st4[2] - st4[0]) * 1e3, 0.0), 1),
+                                              'decode_ms_per_step': round(max(t_a - (st4[2] - st4[0]) * 1e3, 0.0) / max(NEW_TOKENS - 1, 1), 4)},
+                                'ids_equal_the_same_pages_of_the_full_step': same_a},
+            'tile_rank': None if t_b is None else {'rank': rb, 'pages_owned': 0, 'char_tiles': cB, 't_ms': round(t_b, 2)},
+            't_step_ms': round(t_bal, 2),
+            f'projected_speedup_{sw}': round(full_ms / t_bal, 3),
+            **({} if pipelined_ms is None else {f'projected_speedup_{sw}_vs_pipelined_n1': round(pipelined_ms / t_bal, 3)}),
+            'projection_note': 'ms of the one-GPU step / ms of the slower kind of rank; excludes the all-gather (uneven shards padded to the largest: '
+                               f'{sw} x {max(pb["char_counts"])} x 24.5 KB received per rank) and assumes the other ranks of a kind take as long as the one timed'}
+
     # ---- N = 1: one rank's SHARE of BASELINE config 4 as written (64 pages over 8 GPUs), timed on the one GPU there is ----
     # The only evidence for north_star's ">= 6x at 8 GPUs" that can exist without a node: plan ('strong', 64 pages, world 8, rank 0) = 8 pages to own
     # (88 page tiles, 8 prompts, NEW_TOKENS - 1 eight-row decode steps) + an eighth of the character tiles (768), run alone on this GPU, one batch at
@@ -566,53 +618,8 @@ def main():
         # streamed once per step whatever the rows), the others encode more character tiles.  Two kinds of rank, each timed alone on this GPU: the page owner
         # with the most work (its pages' other character tiles come out of the all-gather: made beforehand, handed in) and the rank with the most tiles.
         balanced = None
-        wb0 = plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced')
-        pb = wb0['balanced']
-        if pb['k'] < args.share_world and not args.no_balanced:
-            ra = max(range(args.share_world), key=lambda r: (len(pb['pages'][r]), pb['char_counts'][r], -r))
-            rb = max(range(args.share_world), key=lambda r: (pb['char_counts'][r], -r))
-            nA, cA, cB = len(pb['pages'][ra]), pb['char_counts'][ra], pb['char_counts'][rb]
-
-            def timed_share(w, ins_):
-                step(w=w, inputs=ins_)
-                torch.cuda.synchronize()
-                t0_ = time.perf_counter()
-                out_ = None
-                for _ in range(args.share_steps):
-                    out_ = step(w=w, inputs=ins_)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0_) / args.share_steps * 1e3, out_
-            pseudo_a, _ = model.align_tiles(char_px[:nA * CHAR_TILES])                   # what the gather hands rank A for its pages
-            w_a = {'n_pages': nA, 'mine': list(range(nA)), 'pseudo_all': pseudo_a.reshape(-1, 3, dims.llm_hidden)}
-            t_a, out_a = timed_share(w_a, (page_px[:nA * PAGE_TILES], char_px[:cA], ids[:nA]))
-            st4 = [0.0]
-            torch.cuda.synchronize(); st4[0] = time.perf_counter()
-            step(new_tokens=1, stamps=st4, w=w_a, inputs=(page_px[:nA * PAGE_TILES], char_px[:cA], ids[:nA]))
-            same_a = bool(out_a == full_out[:nA])
-            del pseudo_a, w_a
-            t_b = None
-            if not pb['pages'][rb]:
-                w_b = {'n_pages': 0, 'mine': [], 'pseudo_all': torch.empty((0, 3, dims.llm_hidden), dtype=torch.bfloat16, device=dev)}
-                t_b, _ = timed_share(w_b, (page_px[:0], char_px[:cB], []))
-            t_bal = max(t_a, t_b or 0.0)
-            balanced = {
-                'what': f'the same {args.pages} pages over {args.share_world} GPUs under parallel.plan_balanced: {pb["k"]} ranks own the pages ({nA} rows per decode batch instead of {n_own}; '
-                        'the decode streams the 14.7 GB of weights once per step whatever the rows), all ranks share the character tiles in uneven contiguous shards, still ONE all-gather; '
-                        'the two kinds of rank timed alone on this GPU, one batch at a time',
-                'plan': {'page_owners': pb['k'], 'pages_per_rank': [len(x) for x in pb['pages']], 'char_tiles_per_rank': pb['char_counts'],
-                         'predicted_ms_per_rank': pb['predicted_ms'], 'predicted_even_plan_ms': pb['predicted_even_ms'],
-                         'cost_model': 'callireader_amd/parallel.py: MI355X_COST (ms per tile, per prompt token, per decode step by rows), measured in profiles/round5'},
-                'page_owner_rank': {'rank': ra, 'pages_owned': nA, 'char_tiles': cA, 't_ms': round(t_a, 2),
-                                    'phases_ms': {'visual': round((st4[1] - st4[0]) * 1e3, 1), 'splice_prefill_first_token': round((st4[2] - st4[1]) * 1e3, 1),
-                                                  'decode_remaining_tokens': round(max(t_a - (st4[2] - st4[0]) * 1e3, 0.0), 1),
-                                                  'decode_ms_per_step': round(max(t_a - (st4[2] - st4[0]) * 1e3, 0.0) / max(NEW_TOKENS - 1, 1), 4)},
-                                    'ids_equal_the_same_pages_of_the_full_step': same_a},
-                'tile_rank': None if t_b is None else {'rank': rb, 'pages_owned': 0, 'char_tiles': cB, 't_ms': round(t_b, 2)},
-                't_step_ms': round(t_bal, 2),
-                f'projected_speedup_{args.share_world}': round(full_ms / t_bal, 3),
-                f'projected_speedup_{args.share_world}_vs_pipelined_n1': round((elapsed / args.steps * 1e3) / t_bal, 3),
-                'projection_note': 'ms of the one-GPU step / ms of the slower kind of rank; excludes the all-gather (uneven shards padded to the largest: '
-                                   f'{args.share_world} x {max(pb["char_counts"])} x 24.5 KB received per rank) and assumes the other ranks of a kind take as long as the one timed'}
+        if not args.no_balanced:
+            balanced = measure_balanced(plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced')['balanced'], full_ms, full_out, elapsed / args.steps * 1e3, n_own)
         strong_share = {
             'what': f'one rank\'s share of BASELINE config 4 as written ({args.pages} pages per step over {args.share_world} GPUs, plan_workload(strong, rank 0)) run ALONE on this one GPU, '
                     f'one batch at a time: {n_own} pages owned ({n_own * PAGE_TILES} page tiles, {n_own} prompts of {S_page} tokens, {NEW_TOKENS - 1} decode steps of {n_own} rows) '
@@ -910,7 +917,7 @@ def main():
             torch.cuda.synchronize(); st8[0] = time.perf_counter()
             step(new_tokens=1, stamps=st8)
             t0 = time.perf_counter()
-            step(); torch.cuda.synchronize()
+            out_step8 = step(); torch.cuda.synchronize()
             dt_step8 = time.perf_counter() - t0
             # BASELINE config 5 is config 4 with the fp8 weight path: the same rank-0 share as `strong_share`, both sides with the fp8 options on
             share8 = None
@@ -926,6 +933,10 @@ def main():
                 share8 = {'what': 'strong_share with the fp8 options on (level 2 + e4m3-weight decode) against the fp8 step above: config 5\'s per-rank share',
                           't_share_ms': round(t_s8 * 1e3, 2), 'full_step_ms': round(dt_step8 * 1e3, 1), f'projected_speedup_{args.share_world}': round(dt_step8 / t_s8, 3)}
                 del ins8
+                if not args.no_balanced:                     # ... and the balanced plan under the fp8 options' own stage costs
+                    from callireader_amd.parallel import MI355X_COST_FP8
+                    pb8 = plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced', cost=MI355X_COST_FP8)['balanced']
+                    share8['balanced'] = measure_balanced(pb8, dt_step8 * 1e3, out_step8, None, w8s['pages_per_gpu'], cost_name='MI355X_COST_FP8')
             eng.enable_fp8_mfma(False)
             eng.enable_fp8_decode(False)
             result['fp8_mfma'] = {'what': 'one whole step (one batch at a time) with cr_enable_fp8_mfma level 2 and cr_enable_fp8_decode (e4m3 weight copies in their decode layout): ViT QKV / fc1 / fc2, mlp1[1] and all four LLM '

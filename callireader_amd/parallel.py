@@ -111,6 +111,12 @@ MI355X_COST = {
     'decode_ms': {1: 2.97, 2: 3.11, 4: 3.30, 8: 3.88, 12: 4.28, 16: 4.58, 24: 5.65, 32: 6.28, 64: 8.86},
 }
 
+# the same with cr_enable_fp8_mfma level 2 + cr_enable_fp8_decode (BASELINE config 5; profiles/round5: 42_* fp8_mfma phases, 11_* / 14_* decode rows)
+MI355X_COST_FP8 = {
+    'tile_ms': 0.572, 'char_tile_ms': 0.572, 'prefill_ms_per_token': 0.00713,
+    'decode_ms': {1: 2.2, 8: 3.04, 16: 3.54, 32: 4.75, 64: 7.97},
+}
+
 
 def decode_step_ms(rows, cost=MI355X_COST):
     """Piecewise-linear reading of the measured decode table (beyond its last point: the last slope)."""
