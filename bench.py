@@ -68,7 +68,7 @@ def build_ids(n_page_tiles, n_char_tiles, text_tokens, img_id, ref_id, seed):
     return torch.cat([head, torch.full((n_page_tiles * 256,), img_id), torch.full((n_char_tiles * 3,), ref_id), tail])
 
 
-def plan_workload(scaling, pages, total_pages, world, rank, plan='even', cost=None):
+def plan_workload(scaling, pages, total_pages, world, rank, plan='even', cost=None, owners=None):
     """Which pages and which character tiles one rank handles in a step.  weak: `pages` per GPU whatever N (n_pages = pages * world);
     strong: `total_pages` per step over all ranks (BASELINE config 4 as written: 64 pages over 8 GPUs).  plan 'even': pages are owned
     round-robin, the flat list of character tiles is split contiguously and evenly; plan 'balanced' (strong only): fewer ranks own pages
@@ -81,7 +81,7 @@ def plan_workload(scaling, pages, total_pages, world, rank, plan='even', cost=No
         if scaling != 'strong':
             raise ValueError('the balanced plan is a strong-scaling plan')
         from callireader_amd.parallel import MI355X_COST
-        pb = plan_balanced(n_pages, world, PAGE_TILES, CHAR_TILES, PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS, NEW_TOKENS, cost=cost or MI355X_COST)
+        pb = plan_balanced(n_pages, world, PAGE_TILES, CHAR_TILES, PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS, NEW_TOKENS, cost=cost or MI355X_COST, owners=owners)
         lo, hi = pb['char_bounds'][rank]
         return {'scaling': scaling, 'plan': 'balanced', 'n_pages': n_pages, 'mine': pb['pages'][rank], 'ct_lo': lo, 'ct_hi': hi, 'ct_counts': pb['char_counts'],
                 'pages_per_gpu': len(pb['pages'][rank]), 'balanced': pb}
@@ -290,6 +290,7 @@ def main():
     ap.add_argument('--no-strong-block', action='store_true',
                     help='N > 1 with weak scaling: do not append the strong-scaling block (BASELINE config 4 as written: --total-pages per step over all ranks) to the line')
     ap.add_argument('--strong-steps', type=int, default=2, help='timed steps of that block')
+    ap.add_argument('--balanced-owners', type=int, default=None, help='strong_share.balanced: fix the number of page owners instead of taking the cost model\'s (a sweep shows where its optimum lies)')
     ap.add_argument('--no-balanced', action='store_true', help='do not run the balanced strong-scaling plan (strong_scaling.balanced at N > 1, strong_share.balanced at N = 1)')
     ap.add_argument('--no-strong-share', action='store_true', help='N = 1: do not time one rank\'s share of the strong-scaling step (strong_share)')
     ap.add_argument('--share-world', type=int, default=8, help='the world size whose rank-0 share strong_share runs on this one GPU')
@@ -619,7 +620,8 @@ def main():
         # with the most work (its pages' other character tiles come out of the all-gather: made beforehand, handed in) and the rank with the most tiles.
         balanced = None
         if not args.no_balanced:
-            balanced = measure_balanced(plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced')['balanced'], full_ms, full_out, elapsed / args.steps * 1e3, n_own)
+            balanced = measure_balanced(plan_workload('strong', args.pages, args.pages, args.share_world, 0, plan='balanced', owners=args.balanced_owners)['balanced'],
+                                        full_ms, full_out, elapsed / args.steps * 1e3, n_own)
         strong_share = {
             'what': f'one rank\'s share of BASELINE config 4 as written ({args.pages} pages per step over {args.share_world} GPUs, plan_workload(strong, rank 0)) run ALONE on this one GPU, '
                     f'one batch at a time: {n_own} pages owned ({n_own * PAGE_TILES} page tiles, {n_own} prompts of {S_page} tokens, {NEW_TOKENS - 1} decode steps of {n_own} rows) '

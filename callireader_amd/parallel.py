@@ -107,29 +107,38 @@ MI355X_COST = {
     'tile_ms': 0.71,                 # one 448 x 448 page tile through ViT + mlp1 ...
     'char_tile_ms': 0.70,            # ... one character tile through ViT + mlp1 + resampler + VQ + de-norm in long runs (1 711 tiles: 1 195 ms, 36_*)
     'prefill_ms_per_token': 0.011,   # 34.6 ms per 3 164-token page (splice + prefill + first token of 13 pages: 450 ms)
-    # one decode step of n rows at ~3 200 cached tokens per row (weights 14.7 GB once + 53 MB of KV per row): linear between the points
+    # one decode step of n rows at ~3 200 cached tokens per row (weights 14.7 GB once + 131 KB of KV per row and cached token): linear between the points
     'decode_ms': {1: 2.97, 2: 3.11, 4: 3.30, 8: 3.88, 12: 4.28, 16: 4.58, 24: 5.65, 32: 6.28, 64: 8.86},
+    'decode_ctx_tokens': 3228,            # the context the table was measured at (3 164-token prompt + half of 128 new tokens) ...
+    'decode_ms_per_row_token': 2.4e-5,    # ... and what a row's step costs per cached token more or less (131 KB at ~5.5 TB/s)
 }
 
 # the same with cr_enable_fp8_mfma level 2 + cr_enable_fp8_decode (BASELINE config 5; profiles/round5: 42_* fp8_mfma phases, 11_* / 14_* decode rows)
 MI355X_COST_FP8 = {
     'tile_ms': 0.572, 'char_tile_ms': 0.572, 'prefill_ms_per_token': 0.00713,
     'decode_ms': {1: 2.2, 8: 3.04, 16: 3.54, 32: 4.75, 64: 7.97},
+    'decode_ctx_tokens': 3228, 'decode_ms_per_row_token': 2.4e-5,      # (the KV cache stays bf16)
 }
 
 
-def decode_step_ms(rows, cost=MI355X_COST):
-    """Piecewise-linear reading of the measured decode table (beyond its last point: the last slope)."""
+def decode_step_ms(rows, cost=MI355X_COST, ctx_tokens=None):
+    """Piecewise-linear reading of the measured decode table (beyond its last point: the last slope); ctx_tokens: the rows' mean cached tokens
+    when they differ from the table's (the KV-cache stream is the part of a step that grows with the context)."""
     if rows <= 0:
         return 0.0
     pts = sorted(cost['decode_ms'].items())
     if rows <= pts[0][0]:
-        return float(pts[0][1])
-    for (r0, t0), (r1, t1) in zip(pts, pts[1:]):
-        if rows <= r1:
-            return t0 + (t1 - t0) * (rows - r0) / (r1 - r0)
-    (r0, t0), (r1, t1) = pts[-2], pts[-1]
-    return t1 + (t1 - t0) * (rows - r1) / (r1 - r0)
+        t = float(pts[0][1])
+    else:
+        (r0, t0), (r1, t1) = pts[-2], pts[-1]
+        t = t1 + (t1 - t0) * (rows - r1) / (r1 - r0)
+        for (r0, t0), (r1, t1) in zip(pts, pts[1:]):
+            if rows <= r1:
+                t = t0 + (t1 - t0) * (rows - r0) / (r1 - r0)
+                break
+    if ctx_tokens is not None and 'decode_ctx_tokens' in cost:
+        t = max(t + rows * (ctx_tokens - cost['decode_ctx_tokens']) * cost.get('decode_ms_per_row_token', 0.0), 0.25 * t)
+    return t
 
 
 def _per_page(x, n, what):
@@ -168,7 +177,7 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
             load[r] += page_ms[p]
             pages[r].append(p)
         pages = [sorted(x) for x in pages] + [[] for _ in range(world - k)]
-        fixed = [sum(page_ms[p] for p in x) + ((new_tokens - 1) * decode_step_ms(len(x), cost) if x else 0.0) for x in pages]
+        fixed = [sum(page_ms[p] for p in x) + ((new_tokens - 1) * decode_step_ms(len(x), cost, sum(tok[p] for p in x) / len(x) + new_tokens / 2) if x else 0.0) for x in pages]
         return pages, fixed
 
     def fill(fixed):

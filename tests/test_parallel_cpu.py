@@ -111,6 +111,8 @@ def test_plan_balanced_is_a_partition_and_never_worse_than_the_even_split():
     deterministic, and its predicted step is never slower than the even split's under the same cost model (k = world is among the candidates)."""
     assert decode_step_ms(8) == MI355X_COST['decode_ms'][8] and decode_step_ms(0) == 0.0
     assert MI355X_COST['decode_ms'][8] < decode_step_ms(12) < MI355X_COST['decode_ms'][16] and decode_step_ms(128) > decode_step_ms(64)
+    assert decode_step_ms(16, ctx_tokens=MI355X_COST['decode_ctx_tokens']) == decode_step_ms(16)                 # the table's own context
+    assert decode_step_ms(16, ctx_tokens=500) < decode_step_ms(16) < decode_step_ms(16, ctx_tokens=8000)          # the KV stream grows with the context
     for n_pages, world in [(64, 1), (64, 2), (64, 4), (64, 8), (11, 8), (3, 8), (1, 4), (100, 7)]:
         pl = plan_balanced(n_pages, world, 11, 96, 3164, 128)
         assert pl == plan_balanced(n_pages, world, 11, 96, 3164, 128)
