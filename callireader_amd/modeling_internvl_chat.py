@@ -158,6 +158,9 @@ class InternVLChatModel:
         if boxes is None:
             from . import ordering
             boxes = ordering.acquire_boxes(detect_model, img, self.sorter)      # :346-394, :558 (one helper for chat_ocr and the page batches)
+        if len(boxes) == 0:
+            # the reference reaches torch.cat([]) at :585 with no box on the page
+            raise RuntimeError('calli_align: no character box on the page (the reference fails here too: torch.cat() of an empty list, modeling_internvl_chat.py:585)')
         arr = np.array(img)
         if self.gpu_preprocess:
             # one page upload, every crop resized/padded/normalised by cr_preprocess (replaces the per-box PIL loop :580-583)

@@ -159,6 +159,16 @@ def test_from_pretrained_chat_ocr_with_detector_object_and_real_tokenizer(setup)
     assert m.chat_ocr(tok, det, p, '这幅书法作品内容是什么？', gen, repetition_penalty=1.2) == exp
 
 
+def test_calli_align_without_a_box_fails_as_the_reference_does(setup):
+    """No character box on the page: the reference reaches torch.cat([]) (modeling_internvl_chat.py:585) -> RuntimeError; same class, said plainly, and the
+    model is usable afterwards."""
+    m, img = setup['model'], setup['img']
+    with pytest.raises(RuntimeError, match='no character box'):
+        m.calli_align(img, None, boxes=[])
+    back, idx = m.calli_align(img, None, boxes=[[10, 20, 110, 140]])
+    assert back.shape == (3, m.dims.llm_hidden) and tuple(idx.shape) == (3,)
+
+
 def test_chat_ocr_pages_equals_per_page_calls(setup):
     m, tok, img = setup['model'], setup['tok'], setup['img']
     rng = np.random.default_rng(1)
