@@ -124,6 +124,22 @@ class InternVLChatModel:
         """models/perceiver_resampler.py:81-100  (T,256,4096) -> (T,3,4096)"""
         return self.engine.resample(image_embeddings)
 
+    @staticmethod
+    def pixel_shuffle(x, scale_factor=0.5):
+        """:283-297, ps_version 'v2': (N, W, H, C) -> (N, W * s, H * s, C / s^2), a pure re-indexing.  Kept for callers of the reference's method; extract_feature does
+        not call it (csrc/vision.hip reads the ViT output in this order while it normalises the rows for mlp1)."""
+        n, w, h, c = x.shape
+        hs, ws = int(h * scale_factor), int(w * scale_factor)
+        x = x.reshape(n, w, hs, int(c / scale_factor)).transpose(1, 2)                    # fold 1 / s of H into the channels
+        x = x.reshape(n, hs, ws, int(c / (scale_factor * scale_factor)))                  # ... then 1 / s of W
+        return x.transpose(1, 2).contiguous()
+
+    @staticmethod
+    def find_coordinates(text):
+        """:642-648: every run of digits in the question, as ints (region_wise: x1, x2, y1, y2)."""
+        import re
+        return [int(n) for n in re.findall(r'\d+', text)]
+
     def align_tiles(self, pixel_values, drop_zero=False, use_hard_vector_quant=False, verbose=False):
         """The tile path of calli_align after the boxes are known (:587-640):
         extract_feature -> resampler -> vq_cos_sim -> (hard VQ) -> (drop_zero) -> sigma/mu de-normalisation.
@@ -314,9 +330,8 @@ class InternVLChatModel:
         if img_path is not None:
             try:
                 if region_wise:
-                    import re
                     img = np.array(Image.open(img_path).convert('RGB'))
-                    x1, x2, y1, y2 = [int(n) for n in re.findall(r'\d+', questions)]     # find_coordinates :642-648
+                    x1, x2, y1, y2 = self.find_coordinates(questions)                    # :661-663
                     sub_img = Image.fromarray(img[y1:y2, x1:x2])
                     questions = '输出图片中所有文字:'
                     pixel_values = load_image(sub_img).to(torch.bfloat16).to(self.device)

@@ -95,3 +95,14 @@ def test_tie_rules_of_the_checker():
     assert not vq_tie_rule(0.0703125, 0.0703125 - 2.0 ** -10, 0.0700, 0.0701)[0]        # two steps apart
     assert not vq_tie_rule(0.0703125, 0.0703125 - 2.0 ** -11, 0.0702, 0.0701)[0]        # HIP's own similarities favour the reference's row
     assert not vq_tie_rule(0.0703125, None, 0.0700, 0.0701)[0]                          # not among the reference's candidates
+
+
+def test_model_surface_helpers_pixel_shuffle_and_find_coordinates():
+    """Two small methods of the reference's InternVLChatModel that callers may use directly (modeling_internvl_chat.py:283-297, 642-648): the pixel shuffle as a
+    re-indexing (the HIP path folds it into a load; this is the tensor form, against the oracle's restatement) and the digit runs of a region-wise question."""
+    from callireader_amd.modeling_internvl_chat import InternVLChatModel
+    from oracle import vision
+    x = torch.randn(3, 32, 32, 24)
+    assert torch.equal(InternVLChatModel.pixel_shuffle(x, 0.5), vision.pixel_shuffle(x, 0.5))
+    assert InternVLChatModel.pixel_shuffle(x).shape == (3, 16, 16, 96)
+    assert InternVLChatModel.find_coordinates('区域 12,340 到 56, 789') == [12, 340, 56, 789] and InternVLChatModel.find_coordinates('无数字') == []
