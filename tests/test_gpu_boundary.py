@@ -169,6 +169,26 @@ def test_calli_align_without_a_box_fails_as_the_reference_does(setup):
     assert back.shape == (3, m.dims.llm_hidden) and tuple(idx.shape) == (3,)
 
 
+def test_chat_ocr_region_wise_is_chat_ocr_on_the_crop(setup):
+    """region_wise=True (modeling_internvl_chat.py:659-666, 674-679): the four numbers in the question are x1, x2, y1, y2 of a crop, the question becomes
+    '输出图片中所有文字:', page tiles and character boxes come from the crop; a detection failure returns '检测失败' instead of raising."""
+    m, tok, img = setup['model'], setup['tok'], setup['img']
+    p = os.path.join(setup['dir'], 'page_region.png')
+    img.save(p)
+    x1, x2, y1, y2 = 100, 500, 40, 420
+    sub = Image.fromarray(np.array(img)[y1:y2, x1:x2])
+    small = [[20, 30, 120, 150], [200, 60, 330, 300], [30, 200, 150, 360]]
+    gen = dict(num_beams=1, max_new_tokens=5, do_sample=False)
+    got = m.chat_ocr(tok, YoloLike(small), p, f'识别区域 {x1} {x2} {y1} {y2}', gen, region_wise=True, repetition_penalty=1.0)
+    want = m.chat_ocr(tok, YoloLike(small), sub, '输出图片中所有文字:', gen, repetition_penalty=1.0)
+    assert got == want
+
+    class Failing:
+        def __call__(self, *a, **k):
+            raise ValueError('detector down')
+    assert m.chat_ocr(tok, Failing(), p, f'{x1} {x2} {y1} {y2}', gen, region_wise=True) == '检测失败'
+
+
 def test_chat_ocr_pages_equals_per_page_calls(setup):
     m, tok, img = setup['model'], setup['tok'], setup['img']
     rng = np.random.default_rng(1)
