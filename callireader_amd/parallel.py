@@ -287,3 +287,84 @@ def plan_even(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens,
     pl['char_bounds'] = [shard_range(pl['char_offsets'][-1], world, r) for r in range(world)]
     pl['predicted_ms'], pl['predicted_step_ms'] = None, pl['predicted_even_ms']
     return pl
+
+
+def chat_ocr_pages_sharded(model, tokenizer, detect_model, images, question, generation_config, boxes_list=None, hard_vq=False, repetition_penalty=1.5,
+                           plan=None, group=None, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+                           ALIGNED_TOKEN='[UNUSED_TOKEN_140]'):
+    """`model.chat_ocr_pages` over the ranks of `group`: every rank calls it with the same pages (paths or PIL images) and gets every page's response -- the one
+    its own single-GPU `chat_ocr(..., use_p=True, drop_zero=False)` call gives (modeling_internvl_chat.py:649-763 per page; the reference has no multi-GPU form).
+
+    Detection + reading order (when `boxes_list` is None) run on rank p % world for page p and the boxes are exchanged as objects; then the flow of
+    `sharded_generate`: each rank crops and encodes ITS contiguous shard of the flat character-box list (GPU resize / pad / normalise, ViT -> mlp1 -> resampler ->
+    VQ -> de-norm), one all-gather of the pseudo-token rows, and the owners of a page (plan_balanced over the pages' real sizes, or `plan`) encode its own
+    tiles, splice, prefill and decode.  drop_zero is not offered here: it makes a page's prompt length depend on the VQ result of tiles another rank encodes."""
+    from PIL import Image
+    import numpy as np
+    from . import ordering
+    from .conversation import get_conv_template
+    from .preprocess import plan_page, plan_char
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_pages = len(images)
+    eng = model.engine
+    hidden = eng.dims.llm_hidden
+    model.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+    pages = [Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB') for im in images]
+    # ---- boxes of every page, in reading order: given, or detected where the page lives and exchanged ----
+    if boxes_list is None:
+        mine = {p: [[int(v) for v in b[:4]] for b in ordering.acquire_boxes(detect_model, pages[p], model.sorter)] for p in range(rank, n_pages, world)}
+        if world > 1:
+            got = [None] * world
+            dist.all_gather_object(got, mine, group=group)
+            mine = {k: v for g in got for k, v in g.items()}
+        boxes_list = [mine[p] for p in range(n_pages)]
+    if any(len(b) == 0 for b in boxes_list):
+        raise RuntimeError('chat_ocr_pages_sharded: a page without character boxes (chat_ocr fails on it too: modeling_internvl_chat.py:585)')
+    # ---- prompts (host work, the same on every rank): their lengths are the plan's prefill term ----
+    page_jobs = [plan_page(*pg.size) for pg in pages]                       # (jobs, tiles) per page
+    n_chars = [len(b) for b in boxes_list]
+    template = get_conv_template(model.template)
+    gen = dict(generation_config)
+    gen['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
+    max_new, eos = model._gen_args(gen)
+    ids = []
+    for p in range(n_pages):
+        q = question if '<image>' in question else '<image>\n' + question
+        if ALIGNED_TOKEN not in q:
+            q = q + ALIGNED_TOKEN * (3 * n_chars[p])
+        query, _, _ = model._build_query(q, None, [page_jobs[p][1]], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+        ids.append(tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1))
+    if plan is None:
+        plan = plan_balanced(n_pages, world, [j[1] for j in page_jobs], n_chars, [int(i.numel()) for i in ids], max_new)
+    off = plan['char_offsets']
+    if len(plan['char_counts']) != world or off[-1] != sum(n_chars):
+        raise ValueError('the plan was made for another world size or another batch')
+    # ---- my shard of the flat character-box list ----
+    lo, hi = plan['char_bounds'][rank]
+    parts = []
+    for p in range(n_pages):
+        a, b = max(lo, off[p]), min(hi, off[p + 1])
+        if a >= b:
+            continue
+        w, h = pages[p].size
+        jobs = [plan_char((max(bx[0], 0), max(bx[1], 0), min(bx[2], w), min(bx[3], h)), j) for j, bx in enumerate(boxes_list[p][a - off[p]:b - off[p]])]
+        parts.append(eng.preprocess(torch.from_numpy(np.array(pages[p])), jobs, len(jobs)))
+    if parts:
+        pseudo, _ = model.align_tiles(torch.cat(parts), drop_zero=False, use_hard_vector_quant=hard_vq)
+        pseudo = pseudo.reshape(-1, 3, hidden)
+    else:
+        pseudo = torch.empty((0, 3, hidden), dtype=torch.bfloat16, device=eng.device)
+    finish = all_gather_rows_async(pseudo, off[-1], group, counts=plan['char_counts'])
+    # ---- the pages I own: their tiles under the gather, splice, prefill + decode ----
+    mine = plan['pages'][rank]
+    feats = {p: model.extract_feature(eng.preprocess(torch.from_numpy(np.array(pages[p])), page_jobs[p][0], page_jobs[p][1])) for p in mine}
+    pseudo_all = finish()
+    embeds = [eng.embed_splice(ids[p], feats[p], pseudo_all[off[p]:off[p + 1]], img_id=model.img_context_token_id, ref_id=model.aligned_token_id) for p in mine]
+    outs = model.generate_pages(embeds, max_new, eos, repetition_penalty) if embeds else []
+    result = {p: tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for p, o in zip(mine, outs)}
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, result, group=group)
+        result = {k: v for g in got for k, v in g.items()}
+    return [result[p] for p in range(n_pages)]

@@ -189,6 +189,21 @@ def test_chat_ocr_region_wise_is_chat_ocr_on_the_crop(setup):
     assert m.chat_ocr(tok, Failing(), p, f'{x1} {x2} {y1} {y2}', gen, region_wise=True) == '检测失败'
 
 
+def test_chat_ocr_pages_sharded_over_two_ranks_equals_chat_ocr_pages(ckpt):
+    """parallel.chat_ocr_pages_sharded under torch.distributed.run (two ranks; gloo with both on GPU 0 on a one-GPU box): detection where the page lives, sharded
+    character tiles, one all-gather, page owners by plan (the cost model's, one owner, the even split) -- every page's response is chat_ocr_pages' (scripts/dist_chat_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CR_CKPT_DIR=ckpt['dir'], CR_PARAMS_DIR=ckpt['params'], HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.setdefault('CR_DIST_BACKEND', 'nccl' if torch.cuda.device_count() >= 2 else 'gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29541',
+           os.path.join(root, 'scripts', 'dist_chat_check.py')]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and 'DIST_CHAT OK' in out, out[-3000:]
+
+
 def test_chat_ocr_pages_equals_per_page_calls(setup):
     m, tok, img = setup['model'], setup['tok'], setup['img']
     rng = np.random.default_rng(1)
