@@ -150,7 +150,7 @@ def _per_page(x, n, what):
     return x
 
 
-def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST, owners=None):
+def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST, owners=None, max_rows=64):
     """Strong-scaling plan of one step of `n_pages` pages over `world` ranks.  page_tiles / char_tiles / prompt_tokens: one number for every
     page, or one per page (real pages differ in their character count and prompt length).
 
@@ -158,7 +158,8 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
     with the least work so far -- page p -> rank p % k when all pages are alike; ALL ranks share the flat list of character tiles (page
     order) in contiguous shards sized so that every rank finishes at the same time (a rank whose pages already fill the step gets none).
     k is the one whose slowest rank is fastest under `cost` (or `owners`, when the caller fixes it); k = world with even shards is the
-    even split.  Pure host arithmetic, deterministic: every rank computes the same plan.
+    even split.  No owner gets more than `max_rows` pages while enough ranks exist (64: the rows the weight-streaming decode kernels take in one launch; the
+    table behind `cost` ends there).  Pure host arithmetic, deterministic: every rank computes the same plan.
 
     Returns {'k', 'pages': [[page ids] per rank], 'owner': [rank per page], 'char_counts': [per rank], 'char_bounds': [(lo, hi) per rank],
              'char_offsets': [first flat index per page] + [total], 'predicted_ms': [per rank], 'predicted_step_ms', 'predicted_even_ms'}."""
@@ -204,7 +205,8 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
     if owners is not None and not 1 <= owners <= min(world, n_pages):
         raise ValueError(f'{owners} page owners for {n_pages} pages over {world} ranks')
     best = None
-    for k in ([owners] if owners is not None else range(1, min(world, n_pages) + 1)):
+    k_min = min(-(-n_pages // max_rows), min(world, n_pages)) if max_rows else 1
+    for k in ([owners] if owners is not None else range(k_min, min(world, n_pages) + 1)):
         pages, fixed = assign(k)
         counts = fill(fixed)
         t = [f + c * c_char for f, c in zip(fixed, counts)]

@@ -133,6 +133,8 @@ def test_plan_balanced_is_a_partition_and_never_worse_than_the_even_split():
     # a cost model in which decode steps are free keeps every rank decoding (fewer owners only add prefill + page tiles per owner)
     free = dict(MI355X_COST, decode_ms={1: 0.0, 64: 0.0})
     assert plan_balanced(64, 8, 11, 96, 3164, 128, cost=free)['k'] == 8
+    many = plan_balanced(200, 2, 11, 96, 3164, 128)                                      # 200 pages over 2 ranks: no owner above the 64 rows of a decode launch
+    assert many['k'] == 2 and plan_balanced(200, 2, 11, 96, 3164, 128, max_rows=None)['k'] == 1 and plan_balanced(500, 4, 11, 96, 3164, 128)['k'] == 4
     one = plan_balanced(3, 2, 2, 5, 540, 6, owners=1)                                     # the caller fixes the number of owners (scripts/dist_check.py)
     assert one['k'] == 1 and one['pages'] == [[0, 1, 2], []] and sum(one['char_counts']) == 15
     with pytest.raises(ValueError):
