@@ -176,7 +176,7 @@ def measure_traffic(pages=16):
     prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(prof):
         return None, 'rocprofv3 not found'
-    args = ['--steps', '1', '--warmup', '0', '--pages', str(pages), '--new-tokens', '2', '--no-cpu-baseline', '--no-vit-extra', '--no-pipeline', '--no-traffic', '--no-strong-share']
+    args = ['--steps', '1', '--warmup', '0', '--pages', str(pages), '--new-tokens', '2', '--no-cpu-baseline', '--no-vit-extra', '--no-pipeline', '--no-traffic', '--no-strong-share', '--no-api']
     work = tempfile.mkdtemp(prefix='cr_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
@@ -296,6 +296,8 @@ def main():
     ap.add_argument('--share-world', type=int, default=8, help='the world size whose rank-0 share strong_share runs on this one GPU')
     ap.add_argument('--share-steps', type=int, default=2, help='timed steps of strong_share')
     ap.add_argument('--fp8-extras', action='store_true', help='also time the batched decode on e4m3 weight copies alone (fp8_decode) and compare its first picks with the bf16 decode')
+    ap.add_argument('--no-api', action='store_true', help='N = 1: skip the api_level block (the same batch from JPEG files through chat_ocr_stream / folder_rec to strings)')
+    ap.add_argument('--api-batches', type=int, default=4, help='batches of --pages pages the api_level block streams')
     ap.add_argument('--no-pipeline', action='store_true', help='one batch at a time (the decode of a batch does not run beside the visual stage of the next)')
     args = ap.parse_args()
     NEW_TOKENS = args.new_tokens
@@ -336,7 +338,7 @@ def main():
     n_pages, mine, ct_lo, ct_hi = wl['n_pages'], wl['mine'], wl['ct_lo'], wl['ct_hi']
     P = wl['pages_per_gpu']                              # pages this rank owns per step (round-robin; = --pages with weak scaling)
     S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
-    model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=S_page + NEW_TOKENS + 64, max_pages=P)
+    model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=S_page + NEW_TOKENS + 128, max_pages=P)
     model.img_context_token_id = IMG_CONTEXT_TOKEN_ID
     eng = model.engine
 
@@ -780,6 +782,16 @@ def main():
 
     # ---- extras on rank 0 at N == 1: BASELINE config 2 (ViT only, 32 tiles) and the CPU baseline ----
     if rank == 0 and world == 1:
+        if not args.no_api:
+            # the headline's batch through the reference's API, from image files to strings (benchlib/api.py); untimed extra, same model object
+            from benchlib.api import api_level
+            try:
+                result['api_level'] = api_level(model, ROOT, pages=P, batches=args.api_batches, new_tokens=NEW_TOKENS, folder_pages=2 * P,
+                                                headline_ms_per_step=ms_per_step, headline_pages=n_pages)
+            except Exception as e:                      # never at the cost of the line
+                import traceback
+                traceback.print_exc()
+                result['api_level'] = {'error': f'{type(e).__name__}: {e}'}
         if not args.no_vit_extra:
             px32 = synthetic.make_pixels(32, seed=0, device=dev)
             eng.vit_forward(px32)

@@ -128,16 +128,21 @@ class Engine:
         return out
 
     # ---- tile preprocessing on the GPU ----
-    def preprocess(self, page_u8, jobs, n_tiles):
-        """page_u8: uint8 (H,W,3) RGB tensor (moved to the device once); jobs: dict rows from preprocess.plan_*."""
-        from .preprocess import norm_lut
+    def preprocess(self, page_u8, jobs, n_tiles, out=None):
+        """page_u8: uint8 (H,W,3) RGB tensor (moved to the device once); jobs: dict rows from preprocess.plan_*, or their int32 (n, 11) table
+        (preprocess.jobs_array / plan_chars_array); out: the (n_tiles,3,448,448) bf16 tensor the jobs' tile0 slots index (default: a new one)."""
+        import numpy as np
+        from .preprocess import norm_lut, jobs_array
         if getattr(self, '_lut', None) is None:
             self._lut = norm_lut().to(self.device)
         page = page_u8.to(self.device).contiguous()
         assert page.dtype == torch.uint8 and page.dim() == 3 and page.shape[2] == 3
-        arr = (B.PrepJob * len(jobs))(*[B.PrepJob(**j) for j in jobs])
-        out = torch.empty(n_tiles, 3, self.dims.image_size, self.dims.image_size, device=self.device, dtype=torch.bfloat16)
-        B.check(B.lib.cr_preprocess(self._h, _p(page), page.shape[0], page.shape[1], arr, len(jobs), _p(self._lut), _p(out),
+        tab = np.ascontiguousarray(jobs if isinstance(jobs, np.ndarray) else jobs_array(jobs), dtype=np.int32)
+        assert tab.ndim == 2 and tab.shape[1] * 4 == C.sizeof(B.PrepJob)
+        if out is None:
+            out = torch.empty(n_tiles, 3, self.dims.image_size, self.dims.image_size, device=self.device, dtype=torch.bfloat16)
+        assert out.is_contiguous() and out.shape[0] == n_tiles and out.dtype == torch.bfloat16
+        B.check(B.lib.cr_preprocess(self._h, _p(page), page.shape[0], page.shape[1], tab.ctypes.data_as(C.c_void_p), tab.shape[0], _p(self._lut), _p(out),
                                     n_tiles, _stream()), 'cr_preprocess')
         return out
 

@@ -18,8 +18,25 @@ from .modeling_internvl_chat import InternVLChatModel, load_boxes_json
 IMG_EXT = ('.jpg', '.jpeg', '.png', '.bmp', '.webp')
 
 
+def _sniff(p):
+    """imghdr.what of the reference's utils/utils.py:493-512 (a file is an image when its header says so); the module left the standard library in 3.13: by extension then."""
+    try:
+        import imghdr
+    except ImportError:
+        return 'by-extension' if p.lower().endswith(IMG_EXT) else None
+    try:
+        return imghdr.what(p)
+    except Exception:
+        return None
+
+
 def is_image(p):
-    return os.path.isfile(p) and p.lower().endswith(IMG_EXT)
+    return os.path.isfile(p) and _sniff(p) is not None
+
+
+def get_image_paths(folder_path):
+    """utils/utils.py:493-503: every file under the folder (recursively) whose header is an image's; sorted here, so that the batches and the JSON are reproducible."""
+    return sorted(os.path.join(root, f) for root, _, files in os.walk(folder_path) for f in files if _sniff(os.path.join(root, f)) is not None)
 
 
 def load_detector(params_dir='./params'):
@@ -44,33 +61,81 @@ def boxes_for(image_path, boxes_arg=None, required=True):
 
 
 def single_rec(model, tokenizer, detect_model, generation_config, image_path, prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose,
-               boxes=None):
+               boxes=None, quiet=False):
     bx = None
     if use_p and (boxes is not None or detect_model is None):
         bx = boxes_for(image_path, boxes)
     response, history = model.chat_ocr(tokenizer, detect_model, image_path, prompt, generation_config, use_p=use_p, hard_vq=hard_vq,
                                        drop_zero=drop_zero, repetition_penalty=repetition_penalty, return_history=True,
                                        verbose=verbose, boxes=bx)
-    print(f'User: {prompt}\nAssistant: {response}')
+    if not quiet:
+        print(f'User: {prompt}\nAssistant: {response}')
     return response
 
 
+DEFAULT_BATCH_PAGES = 64       # pages per decode batch in folder mode: the most rows the batched decode kernels take, and the batch the headline is measured on
+
+
 def folder_rec(model, tokenizer, detect_model, generation_config, folder_path, prompt, save_name, use_p, hard_vq, drop_zero, repetition_penalty,
-               verbose):
-    results = []
-    for pic in sorted(f for f in os.listdir(folder_path) if f.lower().endswith(IMG_EXT)):
-        pic_path = os.path.join(folder_path, pic)
+               verbose, batch_pages=DEFAULT_BATCH_PAGES):
+    """inference.py:47-62: every image of the folder -> results JSON [{imagePath, prompt, response}], an image that fails -> "ERROR!" for that entry only.
+    The reference calls chat_ocr image after image; here the images go through `chat_ocr_stream` in batches of `batch_pages` (two batches in flight, files
+    decoded ahead on threads): each response is the one the image's own chat_ocr call gives, pages/s is what changes (batch_pages <= 1: the serial loop).
+    Failures stay per image: a page that cannot be read, has no boxes JSON / no box, or whose prompt is too long is reported alone; if a batch fails as a whole
+    its pages are run one by one, each in its own try/except, as the reference does."""
+    paths = get_image_paths(folder_path)
+    responses = {}
+
+    def one(pic_path):
         try:
-            response = single_rec(model, tokenizer, detect_model, generation_config, pic_path, prompt, use_p, hard_vq, drop_zero,
-                                  repetition_penalty, verbose)
+            return single_rec(model, tokenizer, detect_model, generation_config, pic_path, prompt, use_p, hard_vq, drop_zero, repetition_penalty, verbose,
+                              quiet=True)
         except Exception as e:                               # inference.py:55-57
-            print(f'An error has occured:\n{e}')
+            return e
+
+    def record(pic_path, response):
+        if isinstance(response, BaseException):
+            print(f'An error has occured:\n{response}')
             response = 'ERROR!'
-        results.append({'imagePath': pic_path, 'prompt': prompt, 'response': response})
+        print(f'User: {prompt}\nAssistant: {response}')
+        responses[pic_path] = response
+
+    if batch_pages <= 1 or not hasattr(model, 'chat_ocr_stream'):
+        for pic_path in paths:
+            record(pic_path, one(pic_path))
+    else:
+        # boxes from JSON where there is no detector (single_rec's rule); a page without them fails alone, before the batch is formed
+        boxes, ready = {}, []
+        for pic_path in paths:
+            try:
+                boxes[pic_path] = boxes_for(pic_path) if (use_p and detect_model is None) else None
+                ready.append(pic_path)
+            except Exception as e:
+                responses[pic_path] = e
+        batches = [ready[i:i + batch_pages] for i in range(0, len(ready), batch_pages)]
+        done = 0
+        while done < len(batches):
+            stream = model.chat_ocr_stream(tokenizer, detect_model, batches[done:], prompt, generation_config,
+                                           boxes_batches=[[boxes[p] for p in b] for b in batches[done:]] if (use_p and detect_model is None) else None,
+                                           use_p=use_p, drop_zero=drop_zero, hard_vq=hard_vq, repetition_penalty=repetition_penalty, errors='return')
+            try:
+                for res in stream:
+                    for pic_path, r in zip(batches[done], res):
+                        responses[pic_path] = r
+                    done += 1
+            except Exception as e:
+                print(f'[folder_rec] a batch failed as a whole ({e}); its {len(batches[done])} pages run one by one')
+                for pic_path in batches[done]:
+                    responses[pic_path] = one(pic_path)
+                done += 1
+        for pic_path in paths:                               # the reference's console output and order
+            record(pic_path, responses[pic_path])
+    results = [{'imagePath': p, 'prompt': prompt, 'response': responses[p]} for p in paths]
     if not save_name.endswith('json'):
         save_name += '_result.json'
     with open(save_name, 'w', encoding='utf-8') as f:
-        json.dump(results, f, ensure_ascii=False, indent=2)
+        json.dump(results, f, ensure_ascii=False, indent=4)           # utils/utils.py:59-62 save_json
+    return results
 
 
 def main(argv=None):
@@ -86,6 +151,8 @@ def main(argv=None):
     parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
     parser.add_argument('--params', type=str, default='./params')
     parser.add_argument('--boxes', type=str, default=None, help='labelme-style JSON with ordered character boxes')
+    parser.add_argument('--batch_pages', type=int, default=DEFAULT_BATCH_PAGES,
+                        help='folder mode: pages per batch through chat_ocr_stream (two batches in flight; same responses as the serial loop, which 1 selects)')
     parser.add_argument('--fp8_decode', action='store_true', help='e4m3 weights for the decode (cr_enable_fp8_decode; off by default: the reference computes in bf16)')
     parser.add_argument('--fp8_mfma', type=int, nargs='?', const=1, default=0, choices=(0, 1, 2),
                         help='e4m3 x e4m3 matrix-core linears (cr_enable_fp8_mfma; off by default; a throughput option, not parity-preserving): 1 = the norm-fed linears of the ViT / projector / prefill, 2 = also ViT fc2 and the prefill\'s wo / w2')
@@ -93,7 +160,9 @@ def main(argv=None):
     if not isinstance(args.tgt, str):
         raise ValueError(f'The target should a string, not a instance of {type(args.tgt)}!')
     from .tokenization_internlm2 import InternLM2Tokenizer
-    model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16).eval().cuda()
+    folder = os.path.isdir(args.tgt) and args.batch_pages > 1
+    model = InternVLChatModel.from_pretrained(args.model, params_dir=args.params, torch_dtype=torch.bfloat16,
+                                              **(dict(max_pages=args.batch_pages) if folder else {})).eval().cuda()
     if args.fp8_mfma:
         model.engine.enable_fp8_mfma(True, level=args.fp8_mfma)
     if args.fp8_decode:
@@ -111,7 +180,7 @@ def main(argv=None):
         print('Multiple images recognition mode')
         os.makedirs('results', exist_ok=True)
         folder_rec(model, tokenizer, detect_model, generation_config, args.tgt, args.prompt, os.path.join('results', args.save_name),
-                   args.use_p, args.hard_vq, args.drop_zero, args.repetition_penalty, args.verbose)
+                   args.use_p, args.hard_vq, args.drop_zero, args.repetition_penalty, args.verbose, batch_pages=args.batch_pages)
     else:
         raise ValueError('The target should be either a image path or a folder that contain images!')
 

@@ -446,86 +446,199 @@ class InternVLChatModel:
 
     def chat_ocr_pages(self, tokenizer, detect_model, images, question, generation_config, boxes_list=None, use_p=True,
                        drop_zero=False, hard_vq=False, repetition_penalty=1.5, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>',
-                       IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]'):
+                       IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]', errors='raise'):
         """Many pages at once (new: the reference's chat_ocr is one page per call, evaluate.py loops over it).  The
         character tiles of ALL pages go through the visual stage as one batch, the prompts are prefilled together and
-        the pages decode as one batch; every page gets exactly the response its own chat_ocr call would produce."""
-        embeds, max_new, eos, template = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config, boxes_list, use_p, drop_zero,
-                                                          hard_vq, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN)
-        outs = self.generate_pages(embeds, max_new, eos, repetition_penalty)
-        return [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in outs]
+        the pages decode as one batch; every page gets exactly the response its own chat_ocr call would produce.
+        errors='return': a page whose own chat_ocr call would raise before generation (unreadable image, detector failure, no box, prompt too long) gets that
+        exception object in its slot and the other pages run -- what folder mode's per-image try/except needs (inference.py:55-57)."""
+        embeds, meta = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config, boxes_list, use_p, drop_zero,
+                                        hard_vq, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, errors=errors)
+        outs = self.generate_pages(embeds, meta['max_new'], meta['eos'], repetition_penalty) if embeds else []
+        return self._responses(tokenizer, outs, meta)
+
+    @staticmethod
+    def _responses(tokenizer, outs, meta):
+        """ids of the pages that ran + the exceptions of those that did not -> one entry per page of the batch, in order (:752-753 per page)."""
+        sep = meta['template'].sep
+        res = [None] * meta['n']
+        for i, o in zip(meta['ok'], outs):
+            res[i] = tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(sep)[0].strip()
+        for i, e in meta['failed'].items():
+            res[i] = e
+        return res
 
     def chat_ocr_stream(self, tokenizer, detect_model, image_batches, question, generation_config, boxes_batches=None, use_p=True,
                         drop_zero=False, hard_vq=False, repetition_penalty=1.5, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>',
-                        IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]'):
+                        IMG_CONTEXT_TOKEN='<IMG_CONTEXT>', ALIGNED_TOKEN='[UNUSED_TOKEN_140]', errors='raise', stats=None):
         """chat_ocr_pages over a sequence of page batches with two batches in flight (PagePipeline): a generator that yields one
         list of responses per batch, in order; batch i decodes on a second stream while batch i+1 is detected, tiled, encoded and
-        prefilled.  Every page gets the response of its own chat_ocr call."""
-        pipe, template = None, None
+        prefilled, and the image files of batch i+2 are being decoded on the feeder's threads (pageio.PageFeeder).  Every page gets the
+        response of its own chat_ocr call.  stats (a dict) receives the host seconds per stage and, per batch, how long the compute stream
+        sat between the previous batch's prefill and this batch's first kernel."""
+        pipe, pending = None, None
+        feeder = self._feeder()
+        marks, host0 = [], dict(feeder.stats, tokenize_s=self._tok_s)
+        it = iter(image_batches)
+        boxes_it = iter(boxes_batches) if boxes_batches is not None else None
+
+        def pull():
+            images = next(it, None)
+            if images is None:
+                return None
+            images = list(images)
+            return images, (next(boxes_it) if boxes_it is not None else None), feeder.decode(images)
         try:
-            for b, images in enumerate(image_batches):
-                embeds, max_new, eos, template = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config,
-                                                                  boxes_batches[b] if boxes_batches is not None else None, use_p, drop_zero, hard_vq,
-                                                                  IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN)
+            ahead = pull()
+            while ahead is not None:
+                images, boxes, decoded = ahead
+                ahead = pull()                                  # the next batch's files decode while this one is tiled, encoded and prefilled
+                embeds, meta = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config, boxes, use_p, drop_zero, hard_vq,
+                                                IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, decoded=decoded, errors=errors,
+                                                mark=marks if stats is not None else None)
+                if not embeds:                                  # nothing of this batch reached the language model
+                    if pending is not None:
+                        yield self._responses(tokenizer, pipe.finish(), pending)
+                        pending = None
+                    yield self._responses(tokenizer, [], meta)
+                    continue
                 if pipe is None:
-                    pipe = self.page_pipeline(max_new_tokens=max_new, eos_token_id=eos, repetition_penalty=repetition_penalty)
+                    pipe = self.page_pipeline(max_new_tokens=meta['max_new'], eos_token_id=meta['eos'], repetition_penalty=repetition_penalty)
                 prev = pipe.start(embeds)
-                if prev is not None:
-                    yield [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in prev]
-            last = pipe.finish() if pipe is not None else None
-            if last is not None:
-                yield [tokenizer.batch_decode(torch.tensor([o]), skip_special_tokens=True)[0].split(template.sep)[0].strip() for o in last]
+                if stats is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(torch.cuda.current_stream())
+                    marks.append(('end', e))
+                if pending is not None:
+                    yield self._responses(tokenizer, prev, pending)
+                pending = meta
+            if pending is not None:
+                done, pending = pending, None
+                yield self._responses(tokenizer, pipe.finish(), done)
         finally:
+            if ahead is not None:
+                for f in ahead[2]:
+                    f.cancel()
             if pipe is not None:
                 pipe.close()
+            if stats is not None:
+                torch.cuda.current_stream().synchronize()
+                idle, last_end = [], None
+                for kind, e in marks:
+                    if kind == 'begin' and last_end is not None:
+                        idle.append(round(last_end.elapsed_time(e), 2))
+                    elif kind == 'end':
+                        last_end = e
+                stats['compute_stream_idle_ms_between_batches'] = idle
+                stats['host'] = {k: v - host0[k] for k, v in dict(feeder.stats, tokenize_s=self._tok_s).items()}       # this call's share of the feeder's counters
+
+    def _feeder(self):
+        if getattr(self, '_pagefeeder', None) is None:
+            from .pageio import PageFeeder
+            self._pagefeeder = PageFeeder(self)
+            self._tok_cache, self._tok_s = {}, 0.0
+        return self._pagefeeder
+
+    def _prompt_ids(self, tokenizer, q, n_tiles, n_ref, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN):
+        """ids of one page's prompt = tokenizer(query of chat_ocr, :690-726).  A page prompt is ~40 KB of text of which all but ~100 characters are two RUNS of one
+        added token each (256 x tiles <IMG_CONTEXT>, n_ref [UNUSED_TOKEN_140] appended to the question): tokenizers split added tokens out first and
+        tokenise the stretches between them on their own, so the ids are those of the SKELETON (both runs at length one) with the two ids repeated.
+        The skeleton is tokenised once per question; the FIRST page of every skeleton is also tokenised in full and compared -- a tokenizer for which the
+        shortcut does not hold keeps the full path."""
+        t0 = time.perf_counter()
+        ctx = IMG_CONTEXT_TOKEN * (self.num_image_token * n_tiles)
+        appended = n_ref is not None and ALIGNED_TOKEN not in q
+        def full():
+            query, _, _ = self._build_query(q + ALIGNED_TOKEN * n_ref if appended else q, None, [n_tiles], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+            return tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1)
+        ids = None
+        if n_tiles > 0 and (not appended or n_ref > 0) and IMG_CONTEXT_TOKEN not in q:
+            skel, _, _ = self._build_query(q + ALIGNED_TOKEN if appended else q, None, [n_tiles], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
+            skel = skel.replace(ctx, IMG_CONTEXT_TOKEN, 1)
+            key = (id(tokenizer), skel, appended)
+            ent = self._tok_cache.get(key)
+            if ent is None:
+                sid = tokenizer(skel, return_tensors='pt')['input_ids'].reshape(-1)
+                pi = (sid == self.img_context_token_id).nonzero().reshape(-1)
+                pr = (sid == self.aligned_token_id).nonzero().reshape(-1)
+                ent = False
+                if pi.numel() == 1 and (not appended or (pr.numel() == 1 and int(pr[0]) > int(pi[0]))):
+                    ent = (sid, int(pi[0]), int(pr[0]) if appended else None)
+                if ent:
+                    ref = full()
+                    if not torch.equal(self._expand(ent, n_tiles, n_ref), ref):
+                        ent = False
+                    ids = ref
+                if len(self._tok_cache) > 256:
+                    self._tok_cache.clear()
+                self._tok_cache[key] = ent
+            if ent and ids is None:
+                ids = self._expand(ent, n_tiles, n_ref)
+        if ids is None:
+            ids = full()
+        self._tok_s += time.perf_counter() - t0
+        return ids
+
+    def _expand(self, ent, n_tiles, n_ref):
+        sid, pi, pr = ent
+        img = torch.full((self.num_image_token * n_tiles,), self.img_context_token_id, dtype=sid.dtype)
+        if pr is None:
+            return torch.cat([sid[:pi], img, sid[pi + 1:]])
+        return torch.cat([sid[:pi], img, sid[pi + 1:pr], torch.full((n_ref,), self.aligned_token_id, dtype=sid.dtype), sid[pr + 1:]])
 
     def _ocr_embeds(self, tokenizer, detect_model, images, question, generation_config, boxes_list, use_p, drop_zero, hard_vq,
-                    IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN):
-        """Everything of chat_ocr_pages before the language model: the pages' prompt embeddings with both splices done."""
+                    IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, decoded=None, errors='raise', mark=None):
+        """Everything of chat_ocr_pages before the language model: the pages' prompt embeddings with both splices done, and
+        meta = {n, ok: batch indices of the pages in `embeds`, failed: {index: exception}, max_new, eos, template}.  The host side (decode, boxes, tiles) is
+        pageio.PageFeeder's; nothing on this thread's stream waits for a pageable copy."""
         self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
-        pages = [Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB') for im in images]
-        page_px, n_tiles, char_px, n_chars = [], [], [], []
-        for i, page in enumerate(pages):
-            arr = torch.from_numpy(np.array(page))
-            jobs, n = plan_page(*page.size)
-            page_px.append(self.engine.preprocess(arr, jobs, n))
-            n_tiles.append(n)
-            if use_p:
-                bx = boxes_list[i] if boxes_list is not None else None
-                if bx is None:
-                    from . import ordering
-                    bx = ordering.acquire_boxes(detect_model, page, self.sorter)      # exactly what this page's own chat_ocr call does
-                w, h = page.size
-                jobs = [plan_char((max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), w), min(int(b[3]), h)), j) for j, b in enumerate(bx)]
-                char_px.append(self.engine.preprocess(arr, jobs, len(jobs)))
-                n_chars.append(len(jobs))
-        feats = self.extract_feature(torch.cat(page_px))
-        pseudo = None
-        if use_p:
-            feat_c = self.extract_feature(torch.cat(char_px))
-            rs = self.resampler(feat_c)
-            outs = self.engine.vq(rs, with_cos=hard_vq)
-            idx, cos = outs if hard_vq else (outs, None)
+        feeder = self._feeder()
+        batch = feeder.tiles(decoded if decoded is not None else feeder.decode(images), boxes_list, detect_model, use_p, errors)
         template = get_conv_template(self.template)
         generation_config = dict(generation_config)
         generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
-        embeds, toff, coff = [], 0, 0
-        for i in range(len(pages)):
-            q = question if '<image>' in question else '<image>\n' + question
+        max_new, eos = self._gen_args(generation_config)
+        meta = {'n': len(images), 'ok': [], 'failed': dict(batch.failed), 'max_new': max_new, 'eos': eos, 'template': template}
+        if not batch.ok:
+            return [], meta
+        feeder.hand_over(batch)
+        if mark is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            mark.append(('begin', e))
+        feats = self.extract_feature(batch.page_px)
+        if use_p:
+            feat_c = self.extract_feature(batch.char_px)
+            rs = self.resampler(feat_c)
+            outs = self.engine.vq(rs, with_cos=hard_vq)
+            idx, cos = outs if hard_vq else (outs, None)
+        q = question if '<image>' in question else '<image>\n' + question
+        refs, all_ids, coff = [], [], 0
+        for k in range(len(batch.ok)):
             ref = None
             if use_p:
-                sl = slice(coff, coff + n_chars[i])
+                sl = slice(coff, coff + batch.n_chars[k])
                 ref = self.engine.denorm(rs[sl], idx[sl], cos[sl] if cos is not None else None, drop_zero=drop_zero, hard_vq=hard_vq)
-                coff += n_chars[i]
-                if ALIGNED_TOKEN not in q:
-                    q = q + ALIGNED_TOKEN * ref.shape[0]
-            query, _, _ = self._build_query(q, None, [n_tiles[i]], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
-            ids = tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1)
-            embeds.append(self.engine.embed_splice(ids, feats[toff:toff + n_tiles[i]], ref, img_id=self.img_context_token_id,
-                                                   ref_id=self.aligned_token_id))
-            toff += n_tiles[i]
-        max_new, eos = self._gen_args(generation_config)
-        return embeds, max_new, eos, template
+                coff += batch.n_chars[k]
+            refs.append(ref)
+            all_ids.append(self._prompt_ids(tokenizer, q, batch.n_tiles[k], ref.shape[0] if use_p else None, IMG_START_TOKEN, IMG_END_TOKEN,
+                                            IMG_CONTEXT_TOKEN, ALIGNED_TOKEN))
+        ids_dev = torch.cat(all_ids).pin_memory().to(self.device, non_blocking=True)          # ONE asynchronous upload for the batch's prompts
+        embeds, toff, ioff = [], 0, 0
+        for k, i in enumerate(batch.ok):
+            S = all_ids[k].numel()
+            if S + max_new > self.max_tokens:
+                err = ValueError(f'prompt of {S} tokens + {max_new} new exceeds max_tokens={self.max_tokens}')       # _greedy's check, per page
+                if errors == 'raise':
+                    raise err
+                meta['failed'][i] = err
+            else:
+                embeds.append(self.engine.embed_splice(ids_dev[ioff:ioff + S], feats[toff:toff + batch.n_tiles[k]], refs[k], img_id=self.img_context_token_id,
+                                                       ref_id=self.aligned_token_id))
+                meta['ok'].append(i)
+            toff += batch.n_tiles[k]
+            ioff += S
+        return embeds, meta
 
     def batch_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
                    return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',

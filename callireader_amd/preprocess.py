@@ -142,3 +142,29 @@ def plan_char(box, tile, input_size=448):
     width, height = x2 - x1, y2 - y1
     new_w, new_h, left, top, _, _ = char_canvas(width, height, input_size)
     return dict(sx0=x1, sy0=y1, sw=width, sh=height, ow=new_w, oh=new_h, mode=0, tile0=tile, cols=1, left=left, top=top)
+
+
+JOB_FIELDS = ('sx0', 'sy0', 'sw', 'sh', 'ow', 'oh', 'mode', 'tile0', 'cols', 'left', 'top')      # = cr_prep_job (include/callireader_hip.h), eleven int32
+
+
+def jobs_array(jobs):
+    """plan_* dict rows -> int32 (n, 11) array in cr_prep_job's field order (what Engine.preprocess hands to cr_preprocess)."""
+    return np.array([[j[f] for f in JOB_FIELDS] for j in jobs], dtype=np.int32).reshape(-1, len(JOB_FIELDS))
+
+
+def plan_chars_array(boxes, width, height, tile0=0, input_size=448):
+    """plan_char for all boxes of a page at once (boxes clipped to the page as calli_align's numpy slicing clips them), as the int32 table of jobs_array:
+    the same arithmetic in float64 / int64 numpy as char_canvas' Python (a page has ~100 boxes; the per-box Python cost 2.7 ms a page)."""
+    b = np.asarray([[int(v) for v in bx[:4]] for bx in boxes], dtype=np.int64).reshape(-1, 4)
+    x1, y1 = np.maximum(b[:, 0], 0), np.maximum(b[:, 1], 0)
+    x2, y2 = np.minimum(b[:, 2], width), np.minimum(b[:, 3], height)
+    w, h = x2 - x1, y2 - y1
+    longest = np.maximum(np.maximum(w, h), 1).astype(np.float64)                     # (a degenerate box is refused by cr_preprocess, not here)
+    factor = np.where(longest <= 200, 200 / longest, np.where(longest >= 350, 350 / longest, 1.0))
+    new_w, new_h = (w * factor).astype(np.int64), (h * factor).astype(np.int64)      # int() truncation
+    out = np.zeros((len(b), len(JOB_FIELDS)), dtype=np.int32)
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4], out[:, 5] = x1, y1, w, h, new_w, new_h
+    out[:, 7] = tile0 + np.arange(len(b))
+    out[:, 8] = 1
+    out[:, 9], out[:, 10] = (input_size - new_w) // 2, (input_size - new_h) // 2
+    return out

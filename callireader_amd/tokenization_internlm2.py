@@ -20,6 +20,7 @@ reference's model when it is available) and against ids produced with the refere
 import heapq
 import json
 import os
+import re
 import struct
 
 import torch
@@ -104,26 +105,21 @@ class SentencePieceBPE:
             if ty == BYTE:
                 self.byte_id[int(t[3:5], 16)] = i
         self.user_defined.sort(key=len, reverse=True)
-        self._ud_first = {}
-        for t in self.user_defined:
-            self._ud_first.setdefault(t[0], []).append(t)
+        self._ud_re = re.compile('|'.join(re.escape(t) for t in self.user_defined)) if self.user_defined else None
 
     def __len__(self):
         return len(self.pieces)
 
     def _split(self, text):
-        """characters, with user-defined pieces kept whole and frozen"""
-        out, i, n = [], 0, len(text)
-        while i < n:
-            hit = None
-            for t in self._ud_first.get(text[i], ()):             # longest first
-                if text.startswith(t, i):
-                    hit = t
-                    break
-            if hit:
-                out.append((hit, True)); i += len(hit)
-            else:
-                out.append((text[i], False)); i += 1
+        """characters, with user-defined pieces kept whole and frozen (longest piece first at every position: the alternation is sorted by length)"""
+        if self._ud_re is None:
+            return [(c, False) for c in text]
+        out, i = [], 0
+        for m in self._ud_re.finditer(text):
+            out.extend((c, False) for c in text[i:m.start()])
+            out.append((m.group(), True))
+            i = m.end()
+        out.extend((c, False) for c in text[i:])
         return out
 
     def encode_pieces(self, text):
@@ -211,6 +207,7 @@ class InternLM2Tokenizer:
         self.added_tokens_encoder = dict(added_tokens or {})                 # content -> id
         self.added_tokens_decoder = {i: t for t, i in self.added_tokens_encoder.items()}
         self._split_tokens = sorted(self.added_tokens_encoder, key=len, reverse=True)
+        self._split_re = re.compile('(' + '|'.join(re.escape(t) for t in self._split_tokens) + ')') if self._split_tokens else None
         self.all_special_ids = {self.sp_model.unk_id, self.bos_token_id, self.eos_token_id}
         self.all_special_ids.update(self.added_tokens_encoder[t] for t in special_tokens if t in self.added_tokens_encoder)
         self.padding_side = 'right'
@@ -243,28 +240,21 @@ class InternLM2Tokenizer:
         return len(self.sp_model)
 
     def _split_on_added(self, text):
-        """[(chunk, id-or-None)]: longest added token at each position wins; the rest goes to sentencepiece."""
-        out, buf, i, n = [], [], 0, len(text)
-        while i < n:
-            hit = None
-            for t in self._split_tokens:
-                if text.startswith(t, i):
-                    hit = t
-                    break
-            if hit:
-                if buf:
-                    out.append((''.join(buf), None)); buf = []
-                out.append((hit, self.added_tokens_encoder[hit])); i += len(hit)
-            else:
-                buf.append(text[i]); i += 1
-        if buf:
-            out.append((''.join(buf), None))
-        return out
+        """[(chunk, id-or-None)]: longest added token at each position wins; the rest goes to sentencepiece.  One compiled alternation, longest first,
+        split in C: a page prompt is 2 816 x <IMG_CONTEXT> in 40 KB of text, and a per-character Python scan of it cost 10 ms per page."""
+        if self._split_re is None:
+            return [(text, None)] if text else []
+        enc = self.added_tokens_encoder
+        parts = self._split_re.split(text)                         # [chunk, token, chunk, token, ..., chunk]
+        return [(c, enc.get(c) if i & 1 else None) for i, c in enumerate(parts) if c or i & 1]
 
     def encode(self, text, add_special_tokens=True):
         ids = [self.bos_token_id] if (add_special_tokens and self.add_bos_token) else []
         for chunk, tid in self._split_on_added(text):
-            ids.extend([tid] if tid is not None else self.sp_model.encode(chunk))
+            if tid is not None:
+                ids.append(tid)
+            else:
+                ids.extend(self.sp_model.encode(chunk))
         if add_special_tokens and self.add_eos_token:
             ids.append(self.eos_token_id)
         return ids

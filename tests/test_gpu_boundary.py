@@ -218,6 +218,95 @@ def test_chat_ocr_pages_equals_per_page_calls(setup):
     assert streamed == [[singles[0]], [singles[1], singles[0]], [singles[1]]]
 
 
+def _write_folder(setup, d, n_good=5):
+    """a folder as inference.py --tgt takes it: JPEG / PNG pages of different sizes, one truncated JPEG (its header says 'jpeg', its pixels do not load), in a
+    sub-folder too (utils/utils.py:493-503 walks recursively)"""
+    rng = np.random.default_rng(5)
+    os.makedirs(os.path.join(d, 'more'), exist_ok=True)
+    names = []
+    for k in range(n_good):
+        w, h = [(640, 500), (900, 460), (500, 1200), (448, 448), (1300, 700)][k % 5]
+        im = Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8))
+        name = os.path.join(d, 'more' if k == 3 else '', f'p{k}.{"png" if k == 1 else "jpg"}')
+        im.save(name, **({} if k == 1 else {'quality': 92}))
+        names.append(name)
+    good = open(names[0], 'rb').read()
+    bad = os.path.join(d, 'p2_truncated.jpg')
+    open(bad, 'wb').write(good[:len(good) // 3])
+    open(os.path.join(d, 'notes.txt'), 'w').write('not an image')
+    return sorted(names + [bad]), bad
+
+
+def test_chat_ocr_stream_from_files_equals_chat_ocr_and_a_bad_page_fails_alone(setup, tmp_path):
+    """the batched calls fed from FILE PATHS (decode on threads one batch ahead, tiles on the feeder's stream and context, prompt ids from the
+    skeleton): every response is the page's own chat_ocr call's; errors='return' puts the exception of an unreadable page / a page without a box in its slot."""
+    m, tok = setup['model'], setup['tok']
+    paths, bad = _write_folder(setup, str(tmp_path))
+    det = YoloLike(setup['raw'][:3])
+    gen = dict(num_beams=1, max_new_tokens=5, do_sample=False)
+    q = '读出图中所有文字。'
+    want = {}
+    for p in paths:
+        try:
+            want[p] = m.chat_ocr(tok, det, p, q, gen, repetition_penalty=1.0)
+        except Exception as e:
+            want[p] = type(e)
+    assert want[bad] is FileNotFoundError and sum(isinstance(v, str) for v in want.values()) == 5
+    batches = [paths[:2], paths[2:5], paths[5:]]
+    stats = {}
+    got = list(m.chat_ocr_stream(tok, det, batches, q, gen, repetition_penalty=1.0, errors='return', stats=stats))
+    flat = dict(zip(paths, [r for b in got for r in b]))
+    for p in paths:
+        assert (flat[p] == want[p]) if isinstance(want[p], str) else isinstance(flat[p], want[p]), p
+    assert stats['host']['pages'] == len(paths) and len(stats['compute_stream_idle_ms_between_batches']) == len(batches) - 1
+    # errors='raise' (the default) keeps chat_ocr's behaviour for the batch
+    with pytest.raises(FileNotFoundError):
+        m.chat_ocr_pages(tok, det, paths, q, gen, repetition_penalty=1.0)
+    # boxes handed in per page; a page with an empty list fails alone with the reference's RuntimeError, a batch of failures only yields in order
+    boxes = [[list(b) for b in setup['raw'][:3]], [], [list(b) for b in setup['raw'][:2]]]
+    good3 = [p for p in paths if p != bad][:3]
+    res = m.chat_ocr_pages(tok, None, good3, q, gen, boxes_list=boxes, repetition_penalty=1.0, errors='return')
+    assert isinstance(res[1], RuntimeError) and 'no character box' in str(res[1])
+    assert res[0] == m.chat_ocr(tok, None, good3[0], q, gen, boxes=boxes[0], repetition_penalty=1.0)
+    assert res[2] == m.chat_ocr(tok, None, good3[2], q, gen, boxes=boxes[2], repetition_penalty=1.0)
+    out = list(m.chat_ocr_stream(tok, None, [[good3[0]], [bad, good3[1]], [good3[2]]], q, gen, boxes_batches=[[boxes[0]], [None, []], [boxes[2]]],
+                                 repetition_penalty=1.0, errors='return'))
+    assert out[0] == [res[0]] and out[2] == [res[2]] and isinstance(out[1][0], FileNotFoundError) and isinstance(out[1][1], RuntimeError)
+    # drop_zero / hard_vq go through the same batch path
+    a = m.chat_ocr_pages(tok, det, good3[:2], q, gen, repetition_penalty=1.0, drop_zero=True, hard_vq=True)
+    assert a == [m.chat_ocr(tok, det, p, q, gen, repetition_penalty=1.0, drop_zero=True, hard_vq=True) for p in good3[:2]]
+
+
+def test_folder_rec_batched_gives_the_serial_loops_json(setup, tmp_path, capsys):
+    """inference.py:47-62 through chat_ocr_stream: the JSON (imagePath / prompt / response, one entry per image the folder walk finds, "ERROR!" for the one
+    that fails) equals the one the serial per-image loop writes; boxes from JSON when there is no detector, a page without its JSON fails alone."""
+    from callireader_amd import inference as inf
+    m, tok = setup['model'], setup['tok']
+    d = str(tmp_path / 'pages')
+    paths, bad = _write_folder(setup, d)
+    assert inf.get_image_paths(d) == paths                                    # the truncated file's header says jpeg; notes.txt is not listed
+    gen = dict(num_beams=1, max_new_tokens=5, do_sample=False)
+    det = YoloLike(setup['raw'][:3])
+    args = (m, tok, det, gen, d, '读出图中所有文字。')
+    serial = inf.folder_rec(*args, str(tmp_path / 'serial.json'), True, False, False, 1.0, False, batch_pages=1)
+    batched = inf.folder_rec(*args, str(tmp_path / 'batched'), True, False, False, 1.0, False, batch_pages=4)
+    assert batched == serial
+    assert [r['response'] for r in batched].count('ERROR!') == 1 and batched[paths.index(bad)]['response'] == 'ERROR!'
+    assert json.load(open(str(tmp_path / 'batched_result.json'), encoding='utf-8')) == json.load(open(str(tmp_path / 'serial.json'), encoding='utf-8')) == serial
+    assert capsys.readouterr().out.count('An error has occured') == 2
+    # no detector: labelme-style JSON next to each image (examples/0.json's format); one page has none
+    for k, p in enumerate(paths):
+        if p == bad or k == 1:
+            continue
+        w, h = Image.open(p).size
+        shapes = [{'points': [[b[0] / w * 0.5, b[1] / h * 0.5], [b[2] / w * 0.5, b[3] / h * 0.5]]} for b in setup['raw'][:2 + k % 2]]
+        json.dump({'imageHeight': h, 'imageWidth': w, 'shapes': shapes}, open(os.path.splitext(p)[0] + '.json', 'w'))
+    args = (m, tok, None, gen, d, '读出图中所有文字。')
+    serial = inf.folder_rec(*args, str(tmp_path / 's2.json'), True, False, False, 1.0, False, batch_pages=1)
+    batched = inf.folder_rec(*args, str(tmp_path / 'b2.json'), True, False, False, 1.0, False, batch_pages=3)
+    assert batched == serial and [r['response'] for r in batched].count('ERROR!') == 2
+
+
 def test_dynamic_chat_and_generate(setup):
     m, tok, img = setup['model'], setup['tok'], setup['img']
     px = preprocess.load_image(img).to(torch.bfloat16).cuda()

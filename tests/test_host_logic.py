@@ -106,3 +106,67 @@ def test_model_surface_helpers_pixel_shuffle_and_find_coordinates():
     assert torch.equal(InternVLChatModel.pixel_shuffle(x, 0.5), vision.pixel_shuffle(x, 0.5))
     assert InternVLChatModel.pixel_shuffle(x).shape == (3, 16, 16, 96)
     assert InternVLChatModel.find_coordinates('区域 12,340 到 56, 789') == [12, 340, 56, 789] and InternVLChatModel.find_coordinates('无数字') == []
+
+
+def test_plan_chars_array_is_plan_char_for_every_box():
+    """pageio's job tables (numpy, a page at a time) against the per-box Python they replace, clipping included."""
+    rng = np.random.default_rng(7)
+    W, H = 788, 2000
+    boxes = []
+    for _ in range(3000):
+        x1, y1 = int(rng.integers(-20, W - 2)), int(rng.integers(-20, H - 2))
+        boxes.append((x1, y1, x1 + int(rng.integers(1, 900)), y1 + int(rng.integers(1, 900)), 0.9))          # (a fifth value, as detectors give)
+    boxes += [(10, 10, 210, 110), (10, 10, 211, 110), (0, 0, 350, 350), (0, 0, 349, 351), (5, 5, 6, 6), (0, 0, W, H)]   # both sides of the 200 / 350 thresholds
+    tab = preprocess.plan_chars_array(boxes, W, H, tile0=5)
+    ref = preprocess.jobs_array([preprocess.plan_char((max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), W), min(int(b[3]), H)), 5 + j) for j, b in enumerate(boxes)])
+    assert tab.dtype == np.int32 and tab.shape == ref.shape and (tab == ref).all()
+    assert preprocess.plan_chars_array([], W, H).shape == (0, 11)
+
+
+class _Tok:
+    """added tokens split out first, the stretches between them tokenised on their own (what HF tokenizers and the engine's own do)"""
+    def __init__(self, broken=False):
+        from callireader_amd.tokenization_internlm2 import InternLM2Tokenizer
+        self.calls, self.broken = 0, broken
+        self._split = InternLM2Tokenizer.__new__(InternLM2Tokenizer)
+        self.ids = {'<|im_start|>': 9003, '<|im_end|>': 9002, '<img>': 9004, '</img>': 9005, '<IMG_CONTEXT>': 9006, '[UNUSED_TOKEN_140]': 8997}
+
+    def convert_tokens_to_ids(self, t):
+        return self.ids[t]
+
+    def __call__(self, text, return_tensors='pt'):
+        import re
+        self.calls += 1
+        out = [1]
+        for part in re.split('(' + '|'.join(re.escape(t) for t in self.ids) + ')', text):
+            if part in self.ids:
+                out.append(self.ids[part])
+            else:
+                out.extend(10 + (ord(c) % 5000) for c in part)
+        if self.broken and len(out) > 600:
+            out[3] += 1                                   # a tokenizer whose ids depend on the run lengths: the shortcut must notice
+        return {'input_ids': torch.tensor([out])}
+
+
+@pytest.mark.parametrize('broken', [False, True])
+def test_page_prompt_ids_from_the_skeleton_equal_the_full_tokenisation(broken):
+    from callireader_amd.modeling_internvl_chat import InternVLChatModel
+    m = InternVLChatModel.__new__(InternVLChatModel)
+    m.template, m.num_image_token, m._tok_cache, m._tok_s = 'internlm2-chat', 256, {}, 0.0
+    m.system_message = get_conv_template(m.template).system_message
+    tok = _Tok(broken)
+    m.img_context_token_id, m.aligned_token_id = tok.ids['<IMG_CONTEXT>'], tok.ids['[UNUSED_TOKEN_140]']
+    args = ('<img>', '</img>', '<IMG_CONTEXT>', '[UNUSED_TOKEN_140]')
+
+    def full(q, n_tiles, n_ref):
+        qq = q + '[UNUSED_TOKEN_140]' * n_ref if (n_ref is not None and '[UNUSED_TOKEN_140]' not in q) else q
+        query, _, _ = m._build_query(qq, None, [n_tiles], '<img>', '</img>', '<IMG_CONTEXT>')
+        return _Tok(broken)(query)['input_ids'].reshape(-1)
+    q = '<image>\n这幅书法作品内容是什么？'
+    for n_tiles, n_ref in [(11, 288), (3, 30), (13, 750), (2, 0), (7, None), (11, 288)]:
+        assert torch.equal(m._prompt_ids(tok, q, n_tiles, n_ref, *args), full(q, n_tiles, n_ref)), (n_tiles, n_ref)
+    if not broken:
+        assert tok.calls <= 6                          # two skeletons (with / without the appended run), each checked once against the full text; n_ref = 0 takes the full path
+    # a question that already carries the token keeps it as written (:698), and one that carries <IMG_CONTEXT> takes the full path
+    q2 = '<image>\n读' + '[UNUSED_TOKEN_140]' * 4
+    assert torch.equal(m._prompt_ids(tok, q2, 5, 12, *args), full(q2, 5, 12))
