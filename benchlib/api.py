@@ -116,8 +116,11 @@ def api_level(model, root, pages=64, batches=4, new_tokens=128, folder_pages=128
         # ---- the reference's folder mode (inference.py:47-62) on the batched path ----
         fpaths, _ = make_pages(folder_dir, folder_pages, root)
         save = os.path.join(work, 'recognition.json')
+        import contextlib
+        import io
         t0 = time.perf_counter()
-        results = inf.folder_rec(model, tok, None, gen, folder_dir, PROMPT, save, True, False, False, 1.0, False, batch_pages=pages)
+        with contextlib.redirect_stdout(io.StringIO()):         # folder_rec prints every response, as the reference does: stdout carries the bench line only
+            results = inf.folder_rec(model, tok, None, gen, folder_dir, PROMPT, save, True, False, False, 1.0, False, batch_pages=pages)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert len(results) == folder_pages and all(r['response'] != 'ERROR!' for r in results) and os.path.exists(save)

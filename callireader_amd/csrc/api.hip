@@ -392,7 +392,7 @@ int cr_op_decode_attention(int which, const void* q, const void* kc, const void*
     ap.seq_map = seqs; ap.sk_arr = lens; ap.sk_add = 1;
     ap.nsplit = ((max_keys + 63) / 64 + ATTN_SPLIT_TILES - 1) / ATTN_SPLIT_TILES;
     ap.part_ml = scratch; ap.part_o = scratch + (size_t)B * NKV * ap.nsplit * G * 2;
-    ap.q_pos0 = which == 1 ? -1 : 0;                      // (-1: launch_flash_attn_split keeps the matrix-core split kernel, as CR_DECODE_ATTN=0 does for a whole process)
+    ap.force_matrix_core = which == 1;                    // launch_flash_attn_split keeps the matrix-core split kernel, as CR_DECODE_ATTN=0 does for a whole process
     if (launch_flash_attn_split(ap, HD, (hipStream_t)stream) != CR_OK) return cr_fail(CR_ERR_HIP, "cr_op_decode_attention: launch failed");
     return CR_OK;
 }

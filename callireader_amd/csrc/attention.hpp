@@ -25,6 +25,7 @@ struct AttnParams {
     // causal prefill of several pages in ONE launch: batch b is segment seg[4b..4b+3] = {first row, rows, position of the first
     // row, cache slot}: Q / O rows start at `first row` (q_bs / o_bs unused), keys = position + rows, Sq = the longest segment
     const int32_t* seg;
+    bool force_matrix_core;   // decode: keep the matrix-core split kernel even where attention_decode.hip's streaming kernel qualifies (cr_op_decode_attention which = 1: A/B)
 };
 
 constexpr int ATTN_SPLIT_TILES = 4;      // 256 keys per split: depends only on the row's own key count

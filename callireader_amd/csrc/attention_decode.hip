@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const AttnParams p)
 // the shape the kernel is written for: d = 128, four query rows per (batch, head) (the GQA group), splits of 256 keys (ATTN_SPLIT_TILES = 4)
 bool decode_attn_supported(const AttnParams& p, int head_dim) {
     static const bool off = [] { const char* e = getenv("CR_DECODE_ATTN"); return e && e[0] == '0'; }();      // A/B aid: the matrix-core split kernel
-    // (q_pos0 < 0: a caller's request for the matrix-core split kernel, cr_op_decode_attention)
-    return !off && p.q_pos0 >= 0 && head_dim == HD && p.Sq == NQ && ATTN_SPLIT_TILES == 4 && p.q_prescale == 1.0f && p.part_ml && p.part_o && p.nsplit > 0 &&
+    // kv_group == 1: the kernel indexes K / V by blockIdx.y itself, i.e. H counts KV heads and the GQA group is the Sq = 4 query rows
+    return !off && !p.force_matrix_core && p.kv_group == 1 && head_dim == HD && p.Sq == NQ && ATTN_SPLIT_TILES == 4 && p.q_prescale == 1.0f && p.part_ml && p.part_o && p.nsplit > 0 &&
            (p.q_rs & 7) == 0 && (p.q_hs & 7) == 0 && (p.q_bs & 7) == 0 && (p.k_rs & 7) == 0 && (p.v_rs & 7) == 0 && (p.k_hs & 7) == 0 && (p.v_hs & 7) == 0 &&
            (p.k_bs & 7) == 0 && (p.v_bs & 7) == 0 && (p.sk_arr || p.Sk > 0) && p.k_rs > 0 && p.v_rs > 0 && p.k_rs < 65536 && p.v_rs < 65536 &&
            (int64_t)p.nsplit * 256 * (p.k_rs > p.v_rs ? p.k_rs : p.v_rs) < (1ll << 32) &&      // key * row stride stays in the 32-bit per-lane offset

@@ -573,6 +573,15 @@ int llm_finalize(cr_ctx* c, hipStream_t st) {
         t.dtype = CR_BF16; t.shape = {2 * ff, D}; t.bytes = (size_t)2 * ff * D * 2;
         auto old = c->w.find(dn);
         if (old != c->w.end()) { hipFree(old->second.ptr); c->w.erase(old); }
+        // the e4m3 copies derived from the interleaved tensor carry ITS name, not w1's / w3's: cr_load_weight's invalidation (by the reloaded tensor's own name)
+        // cannot see them (round-5 advice).  They go with the tensor they were made from, and the fp8 options switch off until cr_enable_fp8_* rebuilds them.
+        for (const char* pre : {"fp8.", "fp8s.", "fp8b.", "fp8dl."}) {
+            auto d8 = c->w.find(std::string(pre) + dn);
+            if (d8 == c->w.end()) continue;
+            hipFree(d8->second.ptr);
+            c->w.erase(d8);
+            c->fp8_decode = false; c->fp8_mfma = 0;
+        }
         CR_HIP(hipMalloc(&t.ptr, t.bytes));
         hipLaunchKernelGGL(interleave8_kernel, dim3(2 * ff), dim3(256), 0, st, (const bf16*)i1->second.ptr,
                            (const bf16*)i3->second.ptr, (bf16*)t.ptr, ff);

@@ -48,6 +48,7 @@ class Engine:
         B.check(B.lib.cr_create(device, C.byref(d), C.byref(h)), 'cr_create')
         self._h = h
         self._kv = []
+        self.fp8_decode, self.fp8_mfma = False, 0          # mirrors of the context's options (parallel.default_cost picks the cost table by them)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -63,6 +64,8 @@ class Engine:
     # ---- weights ----
     def load_weight(self, name, t):
         t = t.detach().contiguous()
+        if not name.startswith('orderformer.'):
+            self.fp8_decode, self.fp8_mfma = False, 0      # cr_load_weight switches the options off with the copies they read
         shape = (C.c_int64 * t.dim())(*t.shape)
         B.check(B.lib.cr_load_weight(self._h, name.encode(), _p(t), _DT[t.dtype], shape, t.dim(),
                                      0 if t.is_cuda else 1, _stream()), f'cr_load_weight({name})')
@@ -91,6 +94,7 @@ class Engine:
         """Batched decode streams e4m3 copies of the LLM's linear weights (one fp32 scale per output row) instead of the
         bf16 ones: half the HBM bytes per step.  Off by default: the reference computes in bf16 (include/callireader_hip.h)."""
         B.check(B.lib.cr_enable_fp8_decode(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_decode')
+        self.fp8_decode = bool(on)
 
     # ---- vision ----
     def enable_fp8_mfma(self, on=True, level=1):
@@ -98,6 +102,7 @@ class Engine:
         matrix cores; level 2: also ViT fc2 and the prefill's wo / w2.  OFF by default (the reference's arithmetic is bf16); a throughput
         option whose accuracy only a real checkpoint can price (evaluate.py --compare_fp8)."""
         B.check(B.lib.cr_enable_fp8_mfma(self._h, (2 if level >= 2 else 1) if on else 0, _stream()), 'cr_enable_fp8_mfma')
+        self.fp8_mfma = ((2 if level >= 2 else 1) if on else 0)
 
     def _chk_pixels(self, px):
         if px.dim() != 4:

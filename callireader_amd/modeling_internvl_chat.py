@@ -487,15 +487,39 @@ class InternVLChatModel:
             if images is None:
                 return None
             images = list(images)
-            return images, (next(boxes_it) if boxes_it is not None else None), feeder.decode(images)
+            return [images, (next(boxes_it) if boxes_it is not None else None), feeder.decode(images), None]
+
+        def tile(item):
+            """uploads + tile kernels of a pulled batch on the feeder's stream; a failure is kept for the batch's own turn"""
+            if item is not None and item[3] is None:
+                try:
+                    item[3] = feeder.tiles(item[2], item[1], detect_model, use_p, errors)
+                except Exception as e:
+                    item[3] = e
+        import collections
+        ahead = collections.deque()              # pulled batches, oldest first: [0] next to run (tiled while its predecessor ran), [1] decoding
+
+        def fill():
+            while len(ahead) < 2:
+                item = pull()
+                if item is None:
+                    return
+                ahead.append(item)
         try:
-            ahead = pull()
-            while ahead is not None:
-                images, boxes, decoded = ahead
-                ahead = pull()                                  # the next batch's files decode while this one is tiled, encoded and prefilled
-                embeds, meta = self._ocr_embeds(tokenizer, detect_model, images, question, generation_config, boxes, use_p, drop_zero, hard_vq,
-                                                IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, decoded=decoded, errors=errors,
+            fill()
+            while ahead:
+                cur = ahead.popleft()
+                tile(cur)
+                if isinstance(cur[3], Exception):
+                    raise cur[3]
+                embeds, meta = self._ocr_embeds(tokenizer, None, cur[0], question, generation_config, None, use_p, drop_zero, hard_vq,
+                                                IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, tiles=cur[3], errors=errors,
                                                 mark=marks if stats is not None else None)
+                # batch i+1's tiles BEFORE this thread blocks for batch i-1's decode: when it comes back the compute stream is close to the end of batch i's
+                # prefill, and the first kernel of batch i+1 must not wait for 64 uploads to be issued (measured: 40-60 ms of idle compute stream per batch)
+                if ahead:
+                    tile(ahead[0])
+                fill()                                          # batch i+2: its files start decoding
                 if not embeds:                                  # nothing of this batch reached the language model
                     if pending is not None:
                         yield self._responses(tokenizer, pipe.finish(), pending)
@@ -516,9 +540,10 @@ class InternVLChatModel:
                 done, pending = pending, None
                 yield self._responses(tokenizer, pipe.finish(), done)
         finally:
-            if ahead is not None:
-                for f in ahead[2]:
-                    f.cancel()
+            for item in ahead:
+                if item is not None:
+                    for f in item[2]:
+                        f.cancel()
             if pipe is not None:
                 pipe.close()
             if stats is not None:
@@ -587,13 +612,13 @@ class InternVLChatModel:
         return torch.cat([sid[:pi], img, sid[pi + 1:pr], torch.full((n_ref,), self.aligned_token_id, dtype=sid.dtype), sid[pr + 1:]])
 
     def _ocr_embeds(self, tokenizer, detect_model, images, question, generation_config, boxes_list, use_p, drop_zero, hard_vq,
-                    IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, decoded=None, errors='raise', mark=None):
+                    IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, tiles=None, errors='raise', mark=None):
         """Everything of chat_ocr_pages before the language model: the pages' prompt embeddings with both splices done, and
         meta = {n, ok: batch indices of the pages in `embeds`, failed: {index: exception}, max_new, eos, template}.  The host side (decode, boxes, tiles) is
         pageio.PageFeeder's; nothing on this thread's stream waits for a pageable copy."""
         self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
         feeder = self._feeder()
-        batch = feeder.tiles(decoded if decoded is not None else feeder.decode(images), boxes_list, detect_model, use_p, errors)
+        batch = tiles if tiles is not None else feeder.tiles(feeder.decode(images), boxes_list, detect_model, use_p, errors)
         template = get_conv_template(self.template)
         generation_config = dict(generation_config)
         generation_config['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)

@@ -49,6 +49,8 @@ def all_gather_rows(local, total, group=None, counts=None):
         return local
     counts = _counts(total, world, counts)
     assert local.shape[0] == counts[dist.get_rank(group)], (local.shape, counts)
+    if total == 0:                                        # pages without a character tile: nothing to exchange, and no zero-byte collective
+        return local[:0]
     mx = max(counts)
     tail = local.shape[1:]
     send = local
@@ -78,6 +80,8 @@ def all_gather_rows_async(local, total, group=None, counts=None):
         return lambda: out
     counts = _counts(total, world, counts)
     assert local.shape[0] == counts[dist.get_rank(group)], (local.shape, counts)
+    if total == 0:
+        return lambda: local[:0]
     mx = max(counts)
     tail = local.shape[1:]
     send = local
@@ -101,6 +105,11 @@ def owned_pages(n_pages, world, rank):
 
 # ---- strong scaling: which ranks decode, and how many character tiles each rank encodes ----
 
+# The one collective: every rank receives world x (largest shard) rows of 24 576 B (ragged shards are padded to the largest).  xGMI is point-to-point, 7 links
+# x ~153 GB/s per GPU (MI355X_MICROARCH.md); an 8-rank all-gather of tens of MB has never been measured here (no node), so the rate is a STATED, conservative
+# fifth of the aggregate link rate, and the latency a typical small-collective figure.  The term only decides between plans whose largest shards differ.
+ALLGATHER_COST = {'allgather_latency_ms': 0.05, 'allgather_gbs': 200.0, 'char_row_bytes': 3 * 4096 * 2}
+
 # Stage costs on one MI355X at InternVL2-8B shapes, bf16 (profiles/round5: 21_bench_N1_default.json phases, 24_final_decode_rows.txt,
 # 35_decode_rows_9_to_32.txt).  Only the RATIOS matter to the plan; a box that is 3 % slower is 3 % slower at everything.
 MI355X_COST = {
@@ -111,6 +120,10 @@ MI355X_COST = {
     'decode_ms': {1: 2.97, 2: 3.11, 4: 3.30, 8: 3.88, 12: 4.28, 16: 4.58, 24: 5.65, 32: 6.28, 64: 8.86},
     'decode_ctx_tokens': 3228,            # the context the table was measured at (3 164-token prompt + half of 128 new tokens) ...
     'decode_ms_per_row_token': 2.4e-5,    # ... and what a row's step costs per cached token more or less (131 KB at ~5.5 TB/s)
+    # a visual-stage call runs in chunks of <= 255 tiles (csrc/vision.hip: next_chunk); every chunk STARTED costs this on top of its tiles (24 layers x 7 launches
+    # of cold start and tail, the weights' first read): ragged shards and pages with few tiles pay it for little work (round 5: "the odd chunks cost ~3 ms of 620")
+    'chunk_tiles': 255, 'chunk_ms': 1.5,
+    **ALLGATHER_COST,
 }
 
 # the same with cr_enable_fp8_mfma level 2 + cr_enable_fp8_decode (BASELINE config 5; profiles/round5: 42_* fp8_mfma phases, 11_* / 14_* decode rows)
@@ -118,6 +131,7 @@ MI355X_COST_FP8 = {
     'tile_ms': 0.572, 'char_tile_ms': 0.572, 'prefill_ms_per_token': 0.00713,
     'decode_ms': {1: 2.2, 8: 3.04, 16: 3.54, 32: 4.75, 64: 7.97},
     'decode_ctx_tokens': 3228, 'decode_ms_per_row_token': 2.4e-5,      # (the KV cache stays bf16)
+    'chunk_tiles': 255, 'chunk_ms': 1.2, **ALLGATHER_COST,
 }
 
 
@@ -150,7 +164,41 @@ def _per_page(x, n, what):
     return x
 
 
-def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST, owners=None, max_rows=64):
+def _chunks(n, cost):
+    return -(-n // cost.get('chunk_tiles', 255)) if n > 0 else 0
+
+
+def gather_ms(counts, world, cost):
+    """The all-gather of the character tiles' pseudo-token rows: world x (largest shard) rows received per rank."""
+    if world <= 1 or not counts or max(counts) == 0:
+        return 0.0
+    return cost.get('allgather_latency_ms', 0.0) + world * max(counts) * cost.get('char_row_bytes', 24576) / (cost.get('allgather_gbs', 200.0) * 1e6)
+
+
+def rank_ms(pages, n_char, pt, ct, tok, new_tokens, cost):
+    """One rank's step under `cost`, without the gather: the character tiles of its shard (one visual call: chunks of <= chunk_tiles), and for a page owner its
+    pages' own tiles (one call), prompts and the decode of its pages as one batch."""
+    t = n_char * cost['char_tile_ms'] + _chunks(n_char, cost) * cost.get('chunk_ms', 0.0)
+    if pages:
+        tiles = sum(pt[p] for p in pages)
+        t += tiles * cost['tile_ms'] + _chunks(tiles, cost) * cost.get('chunk_ms', 0.0) + sum(tok[p] for p in pages) * cost['prefill_ms_per_token']
+        t += (new_tokens - 1) * decode_step_ms(len(pages), cost, sum(tok[p] for p in pages) / len(pages) + new_tokens / 2)
+    return t
+
+
+def evaluate_plan(plan, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=None):
+    """Per-rank ms and the step (slowest rank + the gather) of a plan_balanced / plan_even result under `cost` -- the plan's own model, also used to price a plan
+    made under one cost table with another (tests: constants off by 10 %)."""
+    cost = cost or MI355X_COST
+    n_pages = len(plan['owner'])
+    world = len(plan['char_counts'])
+    pt, ct, tok = _per_page(page_tiles, n_pages, 'page_tiles'), _per_page(char_tiles, n_pages, 'char_tiles'), _per_page(prompt_tokens, n_pages, 'prompt_tokens')
+    g = gather_ms(plan['char_counts'], world, cost)
+    per = [rank_ms(plan['pages'][r], plan['char_counts'][r], pt, ct, tok, new_tokens, cost) + g for r in range(world)]
+    return per, max(per)
+
+
+def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens, cost=MI355X_COST, owners=None, max_rows=64, min_gain=0.02):
     """Strong-scaling plan of one step of `n_pages` pages over `world` ranks.  page_tiles / char_tiles / prompt_tokens: one number for every
     page, or one per page (real pages differ in their character count and prompt length).
 
@@ -158,7 +206,10 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
     with the least work so far -- page p -> rank p % k when all pages are alike; ALL ranks share the flat list of character tiles (page
     order) in contiguous shards sized so that every rank finishes at the same time (a rank whose pages already fill the step gets none).
     k is the one whose slowest rank is fastest under `cost` (or `owners`, when the caller fixes it); k = world with even shards is the
-    even split.  No owner gets more than `max_rows` pages while enough ranks exist (64: the rows the weight-streaming decode kernels take in one launch; the
+    even split.  The model (rank_ms + gather_ms): tiles x ms + a fixed cost per 255-tile chunk started, prompt tokens x ms, the decode table by rows and context,
+    and ONE all-gather whose padded size grows with the largest shard.  A plan with fewer owners than ranks is only taken when the model gives it `min_gain`
+    (2 %) over the best plan with every rank an owner: constants that are off by a few per cent on another box must not turn a tie into a loss.
+    No owner gets more than `max_rows` pages while enough ranks exist (64: the rows the weight-streaming decode kernels take in one launch; the
     table behind `cost` ends there).  Pure host arithmetic, deterministic: every rank computes the same plan.
 
     Returns {'k', 'pages': [[page ids] per rank], 'owner': [rank per page], 'char_counts': [per rank], 'char_bounds': [(lo, hi) per rank],
@@ -167,8 +218,8 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
         raise ValueError((n_pages, world))
     pt, ct, tok = _per_page(page_tiles, n_pages, 'page_tiles'), _per_page(char_tiles, n_pages, 'char_tiles'), _per_page(prompt_tokens, n_pages, 'prompt_tokens')
     total_ct = sum(ct)
-    c_tile, c_char = cost['tile_ms'], cost['char_tile_ms']
-    page_ms = [pt[p] * c_tile + tok[p] * cost['prefill_ms_per_token'] for p in range(n_pages)]
+    c_char = cost['char_tile_ms']
+    page_ms = [pt[p] * cost['tile_ms'] + tok[p] * cost['prefill_ms_per_token'] for p in range(n_pages)]
     by_cost = sorted(range(n_pages), key=lambda p: (-page_ms[p], p))
 
     def assign(k):
@@ -178,41 +229,52 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
             load[r] += page_ms[p]
             pages[r].append(p)
         pages = [sorted(x) for x in pages] + [[] for _ in range(world - k)]
-        fixed = [sum(page_ms[p] for p in x) + ((new_tokens - 1) * decode_step_ms(len(x), cost, sum(tok[p] for p in x) / len(x) + new_tokens / 2) if x else 0.0) for x in pages]
-        return pages, fixed
+        return pages, [rank_ms(x, 0, pt, ct, tok, new_tokens, cost) for x in pages]
+
+    def with_chars(fixed, c):
+        return fixed + c * c_char + _chunks(c, cost) * cost.get('chunk_ms', 0.0)
 
     def fill(fixed):
-        """Character tiles per rank: water-filling to a common finishing time, in whole tiles."""
-        lo, hi = 0.0, max(fixed) + total_ct * c_char
+        """Character tiles per rank: water-filling to a common finishing time, in whole tiles (the per-chunk cost is part of a rank's time)."""
+        def take(f, level):                               # the most tiles a rank with fixed work f finishes by `level`
+            n = int(max(0.0, (level - f) / c_char))
+            while n > 0 and with_chars(f, n) > level:
+                n -= max(1, int((with_chars(f, n) - level) / c_char))
+            return max(n, 0)
+        lo, hi = 0.0, max(fixed) + with_chars(0.0, total_ct)
         for _ in range(64):
             mid = 0.5 * (lo + hi)
-            if sum(max(0.0, (mid - f) / c_char) for f in fixed) >= total_ct:
+            if sum(take(f, mid) for f in fixed) >= total_ct:
                 hi = mid
             else:
                 lo = mid
-        counts = [int(max(0.0, (hi - f) / c_char)) for f in fixed]
+        counts = [take(f, hi) for f in fixed]
         left = total_ct - sum(counts)
         while left > 0:                                   # the tiles lost to rounding down: one at a time to the rank that finishes first
-            r = min(range(world), key=lambda i: (fixed[i] + counts[i] * c_char, i))
+            r = min(range(world), key=lambda i: (with_chars(fixed[i], counts[i] + 1), i))
             counts[r] += 1
             left -= 1
         while left < 0:
-            r = max((i for i in range(world) if counts[i] > 0), key=lambda i: (fixed[i] + counts[i] * c_char, -i))
+            r = max((i for i in range(world) if counts[i] > 0), key=lambda i: (with_chars(fixed[i], counts[i]), -i))
             counts[r] -= 1
             left += 1
         return counts
 
     if owners is not None and not 1 <= owners <= min(world, n_pages):
         raise ValueError(f'{owners} page owners for {n_pages} pages over {world} ranks')
-    best = None
-    k_min = min(-(-n_pages // max_rows), min(world, n_pages)) if max_rows else 1
-    for k in ([owners] if owners is not None else range(k_min, min(world, n_pages) + 1)):
+    k_max = min(world, n_pages)
+    k_min = min(-(-n_pages // max_rows), k_max) if max_rows else 1
+    cands = {}
+    for k in ([owners] if owners is not None else range(k_min, k_max + 1)):
         pages, fixed = assign(k)
         counts = fill(fixed)
-        t = [f + c * c_char for f, c in zip(fixed, counts)]
-        if best is None or max(t) < best['predicted_step_ms'] * (1 - 1e-9):
-            best = {'k': k, 'pages': pages, 'char_counts': counts, 'predicted_ms': [round(x, 2) for x in t], 'predicted_step_ms': max(t)}
-    even_fixed = assign(min(world, n_pages))[1]
+        g = gather_ms(counts, world, cost)
+        t = [with_chars(f, c) + g for f, c in zip(fixed, counts)]
+        cands[k] = {'k': k, 'pages': pages, 'char_counts': counts, 'predicted_ms': [round(x, 2) for x in t], 'predicted_step_ms': max(t)}
+    best = min(cands.values(), key=lambda c: (c['predicted_step_ms'], -c['k']))
+    if owners is None and best['k'] < k_max and best['predicted_step_ms'] > (1.0 - min_gain) * cands[k_max]['predicted_step_ms']:
+        best = cands[k_max]
+    even_fixed = assign(k_max)[1]
     even_ct = shard_counts(total_ct, world)
     bounds, lo = [], 0
     for c in best['char_counts']:
@@ -227,10 +289,81 @@ def plan_balanced(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tok
             owner[p] = r
     return {'k': best['k'], 'pages': best['pages'], 'owner': owner, 'char_counts': best['char_counts'], 'char_bounds': bounds, 'char_offsets': offsets,
             'predicted_ms': best['predicted_ms'], 'predicted_step_ms': round(best['predicted_step_ms'], 2),
-            'predicted_even_ms': round(max(f + c * c_char for f, c in zip(even_fixed, even_ct)), 2)}
+            'predicted_even_ms': round(max(with_chars(f, c) for f, c in zip(even_fixed, even_ct)) + gather_ms(even_ct, world, cost), 2)}
 
 
-def sharded_generate(model, page_tiles, char_tiles, input_ids, *, img_id, ref_id, max_new_tokens, plan=None, group=None, gather_results=True, **generate_kw):
+def default_cost(model=None):
+    """The stage-cost table a plan is made with when the caller passes none: the fp8 table when the engine's fp8 options are on (their stage ratios differ:
+    the visual stage and the prefill gain more than the decode), else the bf16 one.  Both were measured on ONE MI355X box (profiles/round5); on other hardware
+    pass `cost=measure_cost(model)` (or cost='measure')."""
+    eng = getattr(model, 'engine', None)
+    if eng is not None and (getattr(eng, 'fp8_mfma', 0) or getattr(eng, 'fp8_decode', False)):
+        return MI355X_COST_FP8
+    return MI355X_COST
+
+
+def measure_cost(model, group=None, seed=0):
+    """The plan's constants MEASURED on this GPU with this model's weights and options, in about two seconds: two visual calls of different sizes (ms per tile and
+    per chunk started), the same through the resampler + VQ + de-norm for character tiles, one 2 048-token prefill, decode steps at 1 / 8 / 16 / 64 rows on
+    short contexts (the KV-cache term per cached token stays the table's: it is an HBM rate).  With a process group every rank measures (the ranks stay in step)
+    and rank 0's numbers are used by all: every rank must compute the same plan."""
+    import time
+    from . import synthetic
+    eng, dev = model.engine, model.engine.device
+    dims = eng.dims
+    base = dict(default_cost(model))
+    px = synthetic.make_pixels(191, seed=seed, device=dev)
+
+    def timed(fn, reps=1):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    n0, n1 = 47, 191                                   # both single chunks (next_chunk): t(n) = chunk_ms + n * tile_ms
+    tp0, tp1 = timed(lambda: model.extract_feature(px[:n0])), timed(lambda: model.extract_feature(px[:n1]))
+    tc0, tc1 = timed(lambda: model.align_tiles(px[:n0])), timed(lambda: model.align_tiles(px[:n1]))
+    tile_ms, char_ms = (tp1 - tp0) / (n1 - n0), (tc1 - tc0) / (n1 - n0)
+    chunk_ms = max(0.5 * ((tp0 - n0 * tile_ms) + (tc0 - n0 * char_ms)), 0.0)
+    del px
+    S = 2048
+    emb = (torch.randn(S, dims.llm_hidden, generator=torch.Generator().manual_seed(seed)) * 0.02).to(torch.bfloat16).to(dev)
+    rows = [1, 8, 16, 64]
+    ctx = 64
+    kv = eng.kv_alloc(max(rows), S + 64)
+    try:
+        t_pre = timed(lambda: (kv.reset(0), eng.prefill(kv, 0, emb)))
+        kv.reset()
+        eng.prefill_batch(kv, list(range(max(rows))), [emb[:ctx]] * max(rows))
+        dec = {}
+        for r in rows:
+            live = list(range(r))
+            dec[r] = timed(lambda: eng.decode(kv, live), reps=6)
+    finally:
+        kv.free()
+    per_tok = base.get('decode_ms_per_row_token', 2.4e-5)
+    cost = dict(base, tile_ms=round(tile_ms, 4), char_tile_ms=round(char_ms, 4), chunk_ms=round(chunk_ms, 3), prefill_ms_per_token=round(t_pre / S, 5),
+                decode_ms={r: round(t, 3) for r, t in dec.items()}, decode_ctx_tokens=ctx + 4, decode_ms_per_row_token=per_tok, measured=True)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        box = [cost]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        cost = box[0]
+    return cost
+
+
+def _resolve_cost(model, cost, group):
+    if cost is None:
+        return default_cost(model)
+    if cost == 'measure':
+        if getattr(model, '_measured_cost', None) is None:
+            model._measured_cost = measure_cost(model, group)
+        return model._measured_cost
+    return cost
+
+
+def sharded_generate(model, page_tiles, char_tiles, input_ids, *, img_id, ref_id, max_new_tokens, plan=None, cost=None, group=None, gather_results=True, **generate_kw):
     """One step of a batch of pages over the ranks of `group`: the multi-GPU form of `model.generate_pages` (the reference has none: inference.py:47-59
     is a serial page loop).  Every rank calls it with the SAME host-side lists --
 
@@ -240,6 +373,8 @@ def sharded_generate(model, page_tiles, char_tiles, input_ids, *, img_id, ref_id
     -- and encodes only its share: its contiguous shard of the flat character-tile list (ViT -> mlp1 -> resampler -> VQ -> de-norm), ONE all-gather of the
     24.5 KB pseudo-token rows, then, for the pages it owns, their own tiles (ViT -> mlp1, under the gather), the splice, prefill and greedy decode.
     plan: a `plan_balanced` result (default: computed here from the lists' sizes -- fewer, fatter decode batches); `plan_even(...)` for one page owner per rank.
+    cost: the stage-cost table of that default plan -- None: MI355X_COST, or MI355X_COST_FP8 when the engine's fp8 options are on (`default_cost`); 'measure': measured
+    on this GPU once per model (`measure_cost`, ~2 s, rank 0's numbers on every rank); or a table of your own (other hardware).
     Returns {page: ids} for every page (gather_results) or for the pages this rank owns.  Per page the ids are the single-process ids."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -247,7 +382,8 @@ def sharded_generate(model, page_tiles, char_tiles, input_ids, *, img_id, ref_id
     if len(page_tiles) != n_pages or len(char_tiles) != n_pages:
         raise ValueError('page_tiles, char_tiles and input_ids are one entry per page')
     if plan is None:
-        plan = plan_balanced(n_pages, world, [int(t.shape[0]) for t in page_tiles], [int(t.shape[0]) for t in char_tiles], [int(i.numel()) for i in input_ids], max_new_tokens)
+        plan = plan_balanced(n_pages, world, [int(t.shape[0]) for t in page_tiles], [int(t.shape[0]) for t in char_tiles], [int(i.numel()) for i in input_ids], max_new_tokens,
+                             cost=_resolve_cost(model, cost, group))
     if len(plan['char_counts']) != world or plan['char_offsets'][-1] != sum(int(t.shape[0]) for t in char_tiles):
         raise ValueError('the plan was made for another world size or another batch')
     dev = model.engine.device
@@ -262,9 +398,13 @@ def sharded_generate(model, page_tiles, char_tiles, input_ids, *, img_id, ref_id
         pseudo = torch.empty((0, 3, hidden), dtype=torch.bfloat16, device=dev)
     finish = all_gather_rows_async(pseudo, off[-1], group, counts=plan['char_counts'])
     mine = plan['pages'][rank]
-    vit = {}
-    for p in mine:                                       # (pages without tiles of their own exist: c_p only)
-        vit[p] = model.extract_feature(page_tiles[p].to(dev)) if page_tiles[p].shape[0] else None
+    vit = {p: None for p in mine}                        # (pages without tiles of their own exist: c_p only)
+    with_tiles = [p for p in mine if page_tiles[p].shape[0]]
+    if with_tiles:                                       # ONE visual call for the owned pages' tiles (255-tile chunks), not one small chunk per page
+        feats, o = model.extract_feature(torch.cat([page_tiles[p].to(dev) for p in with_tiles])), 0
+        for p in with_tiles:
+            vit[p] = feats[o:o + page_tiles[p].shape[0]]
+            o += page_tiles[p].shape[0]
     pseudo_all = finish()
     embeds = [model.engine.embed_splice(input_ids[p].to(dev), vit[p], pseudo_all[off[p]:off[p + 1]] if off[p + 1] > off[p] else None, img_id=img_id, ref_id=ref_id)
               for p in mine]
@@ -287,12 +427,13 @@ def plan_even(n_pages, world, page_tiles, char_tiles, prompt_tokens, new_tokens,
     pl['owner'] = [p % k for p in range(n_pages)]
     pl['char_counts'] = shard_counts(pl['char_offsets'][-1], world)
     pl['char_bounds'] = [shard_range(pl['char_offsets'][-1], world, r) for r in range(world)]
-    pl['predicted_ms'], pl['predicted_step_ms'] = None, pl['predicted_even_ms']
+    per, step = evaluate_plan(pl, page_tiles, char_tiles, prompt_tokens, new_tokens, cost)
+    pl['predicted_ms'], pl['predicted_step_ms'] = [round(x, 2) for x in per], round(step, 2)
     return pl
 
 
 def chat_ocr_pages_sharded(model, tokenizer, detect_model, images, question, generation_config, boxes_list=None, hard_vq=False, repetition_penalty=1.5,
-                           plan=None, group=None, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+                           plan=None, cost=None, group=None, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
                            ALIGNED_TOKEN='[UNUSED_TOKEN_140]'):
     """`model.chat_ocr_pages` over the ranks of `group`: every rank calls it with the same pages (paths or PIL images) and gets every page's response -- the one
     its own single-GPU `chat_ocr(..., use_p=True, drop_zero=False)` call gives (modeling_internvl_chat.py:649-763 per page; the reference has no multi-GPU form).
@@ -312,15 +453,33 @@ def chat_ocr_pages_sharded(model, tokenizer, detect_model, images, question, gen
     eng = model.engine
     hidden = eng.dims.llm_hidden
     model.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
-    pages = [Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB') for im in images]
-    # ---- boxes of every page, in reading order: given, or detected where the page lives and exchanged ----
+    # ---- pages and the boxes of every page, in reading order: given, or detected where the page lives and exchanged ----
+    # A rank that cannot read a page or whose detector fails must not leave the others waiting in the collective (round-5 advice): every failure becomes a
+    # marker, the markers are exchanged with the boxes, and EVERY rank raises the same error after the exchange.
+    pages, failures = [], {}
+    for p, im in enumerate(images):
+        try:
+            pages.append(Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB'))
+        except Exception as e:
+            pages.append(None)
+            failures[p] = f'page {p}: cannot be read: {type(e).__name__}: {e}'
     if boxes_list is None:
-        mine = {p: [[int(v) for v in b[:4]] for b in ordering.acquire_boxes(detect_model, pages[p], model.sorter)] for p in range(rank, n_pages, world)}
+        mine = {}
+        for p in range(rank, n_pages, world):
+            if pages[p] is None:
+                continue
+            try:
+                mine[p] = [[int(v) for v in b[:4]] for b in ordering.acquire_boxes(detect_model, pages[p], model.sorter)]
+            except Exception as e:
+                failures[p] = f'page {p}: detection failed on rank {rank}: {type(e).__name__}: {e}'
         if world > 1:
             got = [None] * world
-            dist.all_gather_object(got, mine, group=group)
-            mine = {k: v for g in got for k, v in g.items()}
-        boxes_list = [mine[p] for p in range(n_pages)]
+            dist.all_gather_object(got, (mine, failures), group=group)
+            mine = {k: v for g in got for k, v in g[0].items()}
+            failures = {k: v for g in got for k, v in g[1].items()}
+        boxes_list = [mine.get(p, []) for p in range(n_pages)]
+    if failures:
+        raise RuntimeError('chat_ocr_pages_sharded: ' + '; '.join(failures[p] for p in sorted(failures)))
     if any(len(b) == 0 for b in boxes_list):
         raise RuntimeError('chat_ocr_pages_sharded: a page without character boxes (chat_ocr fails on it too: modeling_internvl_chat.py:585)')
     # ---- prompts (host work, the same on every rank): their lengths are the plan's prefill term ----
@@ -338,7 +497,7 @@ def chat_ocr_pages_sharded(model, tokenizer, detect_model, images, question, gen
         query, _, _ = model._build_query(q, None, [page_jobs[p][1]], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
         ids.append(tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1))
     if plan is None:
-        plan = plan_balanced(n_pages, world, [j[1] for j in page_jobs], n_chars, [int(i.numel()) for i in ids], max_new)
+        plan = plan_balanced(n_pages, world, [j[1] for j in page_jobs], n_chars, [int(i.numel()) for i in ids], max_new, cost=_resolve_cost(model, cost, group))
     off = plan['char_offsets']
     if len(plan['char_counts']) != world or off[-1] != sum(n_chars):
         raise ValueError('the plan was made for another world size or another batch')

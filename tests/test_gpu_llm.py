@@ -219,6 +219,48 @@ def test_reloading_a_weight_rebuilds_its_decode_layout(setup):
     a.close(); b.close()
 
 
+def test_reloading_w1_and_w3_with_the_fp8_options_on_rebuilds_their_e4m3_copies(setup):
+    """Round-5 advice (medium): the e4m3 copies of w1|w3 are named after the INTERLEAVED tensor (fp8. / fp8s. / fp8dl.derived.w13.N), which cr_load_weight's
+    invalidation by the reloaded tensor's own name cannot see.  A context with fp8 decode + fp8 prefill on reloads w1 and w3 of one layer, finalizes, re-enables
+    the options and must give a fresh context's logits (prefill: e4m3 x e4m3 w1|w3; decode: e4m3-weight stream) -- and the options are OFF in between."""
+    from callireader_amd.engine import Engine
+    dims, sd = setup['dims'], dict(setup['sd'])
+
+    def run(e):
+        emb = prompt(300, 78).cuda()                                  # >= 256 rows: the prefill takes the e4m3 matrix-core linears
+        kv = e.kv_alloc(1, 512)
+        first = e.prefill(kv, 0, emb, want_logits=True).clone()
+        steps = [e.decode(kv, [0], want_logits=True).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        kv.free()
+        return [first] + steps
+    a = Engine(dims, max_pos=2048)
+    a.load_state_dict(sd); a.load_rope(); a.finalize()
+    a.enable_fp8_mfma(True, level=2); a.enable_fp8_decode(True)
+    before = run(a)
+    g = torch.Generator().manual_seed(10)
+    changed = {}
+    for k in ('language_model.model.layers.0.feed_forward.w1.weight', 'language_model.model.layers.0.feed_forward.w3.weight'):
+        changed[k] = (sd[k].float() + 0.02 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
+        a.load_weight(k, changed[k])
+    a.finalize()
+    bf16_after = run(a)                                               # the options went off with the copies they read
+    a.enable_fp8_mfma(True, level=2); a.enable_fp8_decode(True)
+    after = run(a)
+    sd.update(changed)
+    b = Engine(dims, max_pos=2048)
+    b.load_state_dict(sd); b.load_rope(); b.finalize()
+    plain = run(b)
+    b.enable_fp8_mfma(True, level=2); b.enable_fp8_decode(True)
+    fresh = run(b)
+    for x, y in zip(after, fresh):
+        assert torch.equal(x, y)
+    for x, y in zip(bf16_after, plain):
+        assert torch.equal(x, y)
+    assert not torch.equal(after[0], before[0]) and not torch.equal(after[1], before[1])
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize('rows', [1, 2, 3, 4, 5, 7, 8, 9])
 def test_fused_small_batch_decode_gives_the_separate_kernels_bits(setup, rows):
     """Batches of <= 8 rows decode through gemm_decode.hip (RMSNorm prologues, RoPE + cache-write epilogue, residual-add epilogues: six
