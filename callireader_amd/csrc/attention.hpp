@@ -26,7 +26,17 @@ struct AttnParams {
     // row, cache slot}: Q / O rows start at `first row` (q_bs / o_bs unused), keys = position + rows, Sq = the longest segment
     const int32_t* seg;
     bool force_matrix_core;   // decode: keep the matrix-core split kernel even where attention_decode.hip's streaming kernel qualifies (cr_op_decode_attention which = 1: A/B)
+    // decode with RoPE + split FOLDED IN (attention_decode.hip, 9..64-row batches): instead of reading Q and finding the new token's K / V row in the cache, the
+    // kernel sums wqkv's K-slice partial sums [qkv_splits][B][qkv_ld] fp32 itself (slice order, rounded once), rotates q and k (rope_split_kernel's arithmetic) and
+    // the workgroup whose split holds the new position writes the K / V row to the cache.  Row layout of qkv: [H groups][4 q | k | v][128].
+    const float* qkv_part;
+    int qkv_splits;
+    int64_t qkv_ld;
+    const bf16* rope_cos;     // [max_pos][128]
+    const bf16* rope_sin;
 };
+
+bool decode_attn_fold_supported(const AttnParams& p, int head_dim);
 
 constexpr int ATTN_SPLIT_TILES = 4;      // 256 keys per split: depends only on the row's own key count
 

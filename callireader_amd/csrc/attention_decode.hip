@@ -43,10 +43,20 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-template <bool DIV>
+constexpr int FOLD_MAX_SPLITS = 8;       // K-slices of the wqkv partial-sum GEMM the folded prologue takes (gemm_skinny.hip: partial_geom gives 2..8)
+
+// FOLD: RoPE + split + the cache write of the new token inside this kernel (round-5 verdict, item 3: the 9..64-row decode step ran rope_split_kernel as a
+// launch of its own, 6.9 us of a 13-row layer's 133).  Threads 0..95 = (slot 0..5 [4 q heads | k | v], 16-byte chunk c) of this (row, KV group) -- exactly
+// rope_split_kernel's thread -- request their chunk of every K-slice BEFORE the K / V stream (loads return in order: the sums then wait for 16 loads, not for the
+// stream), add the slices in slice order from 0.f, round once, and rotate with the partner chunk (c + 8) & 15 fetched by a DPP row rotation (the 16 chunks of a
+// slot are one DPP row); the six bf16 rows meet in 1.5 KiB of LDS behind one barrier.  q is read from there; the workgroup whose split holds the new position also
+// stores the K / V row to the cache and puts it into the registers of the lanes that would have loaded it (every lane at or past the new position: the cache row
+// itself is not written yet when they load it).  The same fp32 sums, the same roundings: a row's bits do not depend on which form its batch takes.
+template <bool DIV, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) float s_o[16][NQ][HD];      // the workgroup's 16 partials: un-normalised O ...
     __shared__ float s_ml[16][NQ][2];                                   // ... maximum and row sum
+    __shared__ __attribute__((aligned(16))) bf16x8 s_qkv[FOLD ? 6 : 1][16];   // FOLD: the rotated q heads, the new K row, the new V row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
@@ -68,10 +78,23 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const AttnParams p)
     // the query rows first, then all 32 K / V loads behind them, and NOTHING else in between: loads return in order, so the first use of q waits for four
     // loads, not for the stream (left to itself the scheduler consumed q before it had issued the stream: a round trip with nothing in flight)
     bf16x8 q[NQ];
-    {
+    f32x4 pv[FOLD ? FOLD_MAX_SPLITS : 1][2];
+    bf16x8 rc = {}, rs = {};
+    const int fslot = tid >> 4;                               // FOLD: threads 0..95 = (slot, chunk c)
+    if (!FOLD) {
         const bf16* qp = p.Q + (int64_t)batch * p.q_bs + (int64_t)head * p.q_hs + lane_off;
 #pragma unroll
         for (int h = 0; h < NQ; h++) q[h] = *(const bf16x8*)(qp + (int64_t)h * p.q_rs);
+    } else if (fslot < 6) {
+        const float* pp = p.qkv_part + (int64_t)batch * p.qkv_ld + (head * 6 + fslot) * HD + c * 8;
+        const int64_t sstep = (int64_t)gridDim.z * p.qkv_ld;
+#pragma unroll
+        for (int s = 0; s < FOLD_MAX_SPLITS; s++) {
+            const f32x4* ps = (const f32x4*)(pp + (int64_t)min(s, p.qkv_splits - 1) * sstep);
+            pv[s][0] = ps[0]; pv[s][1] = ps[1];
+        }
+        rc = *(const bf16x8*)(p.rope_cos + (int64_t)(Sk - 1) * HD + c * 8);
+        rs = *(const bf16x8*)(p.rope_sin + (int64_t)(Sk - 1) * HD + c * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 kr[IT], vr[IT];
@@ -80,6 +103,47 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const AttnParams p)
 #pragma unroll
     for (int i = 0; i < IT; i++) vr[i] = __builtin_nontemporal_load((const bf16x8*)(Vb + ((unsigned)min(key0 + 4 * i, Sk - 1) * v_rs + lane_off)));
     __builtin_amdgcn_sched_barrier(0);
+    if (FOLD) {
+        const bool new_here = (Sk - 1) >> 8 == split;         // this workgroup's split holds the new token's position (workgroup-uniform)
+        if (fslot < 6) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < FOLD_MAX_SPLITS; s++)
+                if (s < p.qkv_splits) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { a[e] += pv[s][0][e]; a[4 + e] += pv[s][1][e]; }
+                }
+            bf16x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = f2bf(a[e]);
+            bf16x8 y = x;
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            const i32x4_t xi = __builtin_bit_cast(i32x4_t, x);
+            i32x4_t xpi;
+#pragma unroll
+            for (int e = 0; e < 4; e++) xpi[e] = __builtin_amdgcn_update_dpp(0, xi[e], 0x128, 0xf, 0xf, true);      // row_ror:8: chunk (c + 8) & 15 of the same slot
+            if (fslot < 5) {
+                const bf16x8 xp = __builtin_bit_cast(bf16x8, xpi);
+                const float sign = c < 8 ? -1.0f : 1.0f;       // rotate_half: (-x2, x1)
+#pragma unroll
+                for (int e = 0; e < 8; e++) y[e] = f2bf(rbf(bf2f(x[e]) * bf2f(rc[e])) + rbf(sign * bf2f(xp[e]) * bf2f(rs[e])));
+            }
+            s_qkv[fslot][c] = y;
+            if (new_here && fslot >= 4) {                       // the cache row of the new token (read by the next steps)
+                bf16* dst = const_cast<bf16*>(fslot == 4 ? Kb : Vb) + ((unsigned)(Sk - 1) * (fslot == 4 ? k_rs : v_rs) + lane_off);
+                *(bf16x8*)dst = y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NQ; h++) q[h] = s_qkv[h][c];
+        if (new_here) {
+            const bf16x8 kn = s_qkv[4][c], vn = s_qkv[5][c];
+#pragma unroll
+            for (int i = 0; i < IT; i++)
+                if (key0 + 4 * i >= Sk - 1) { kr[i] = kn; vr[i] = vn; }
+        }
+    }
     const float inv_div = 1.0f / p.s_div;
 
     // ---- scores of this lane's own query head for its group's 16 keys ----
@@ -178,9 +242,20 @@ bool decode_attn_supported(const AttnParams& p, int head_dim) {
            (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.part_o & 7) == 0;      // 16-byte loads, 8-byte partial stores
 }
 
+// the folded form on top: partial sums of the [H groups][4 q | k | v][128] row, at most FOLD_MAX_SPLITS slices, one new token per row at position sk_arr[slot]
+bool decode_attn_fold_supported(const AttnParams& p, int head_dim) {
+    return decode_attn_supported(p, head_dim) && p.qkv_part && p.rope_cos && p.rope_sin && p.qkv_splits >= 1 && p.qkv_splits <= FOLD_MAX_SPLITS &&
+           p.sk_arr && p.sk_add == 1 && p.k_rs == HD && p.v_rs == HD && (p.qkv_ld & 3) == 0 && p.qkv_ld >= (int64_t)p.H * 6 * HD &&
+           (((uintptr_t)p.qkv_part | (uintptr_t)p.rope_cos | (uintptr_t)p.rope_sin) & 15) == 0;
+}
+
 int launch_decode_attn(const AttnParams& p, hipStream_t stream) {
     const dim3 grid(p.nsplit, p.H, p.B);
-    if (p.s_div != 1.0f) hipLaunchKernelGGL(decode_attn_kernel<true>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(decode_attn_kernel<false>, grid, dim3(256), 0, stream, p);
+    if (p.qkv_part) {
+        if (!decode_attn_fold_supported(p, HD)) return CR_ERR_ARG;
+        if (p.s_div != 1.0f) hipLaunchKernelGGL((decode_attn_kernel<true, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((decode_attn_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    } else if (p.s_div != 1.0f) hipLaunchKernelGGL((decode_attn_kernel<true, false>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((decode_attn_kernel<false, false>), grid, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? CR_OK : CR_ERR_HIP;
 }

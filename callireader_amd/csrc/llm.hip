@@ -437,13 +437,23 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
                                : gemm(c, EPI_PARTIAL, h, D, w.wqkv, D, pbuf, QKV, nullptr, 0, M, QKV, D, st, false, w.d_qkv, 2));
         else CR_TRY(f8 ? gemm8(c, EPI_STORE, h, D, w.q_qkv, w.s_qkv, qkv, QKV, nullptr, 0, M, QKV, D, st, w.l_qkv)
                         : gemm(c, EPI_STORE, h, D, w.wqkv, D, qkv, QKV, nullptr, 0, M, QKV, D, st, !decode));
-        hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
-                           decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens,
-                           (const float*)(sliced ? pbuf : nullptr), s_qkv);
         AttnParams ap{};
         ap.K = kc; ap.V = vc; ap.Q = q; ap.O = ao;
         ap.k_bs = ap.v_bs = (int64_t)NKV * kv->max_tokens * HD; ap.k_rs = ap.v_rs = HD; ap.k_hs = ap.v_hs = (int64_t)kv->max_tokens * HD;
         ap.q_prescale = 1.0f; ap.s_div = 11.313708498984761f;      // math.sqrt(128)
+        // decode, 9..64 rows: RoPE + split + the new token's cache row are folded into the attention kernel (attention_decode.hip, FOLD) where it qualifies
+        bool rope_folded = false;
+        if (sliced && c->fold_rope) {
+            AttnParams fp = ap;
+            fp.q_bs = D; fp.q_rs = HD; fp.q_hs = 4 * HD; fp.B = M; fp.H = NKV; fp.Sq = NH / NKV; fp.kv_group = 1; fp.sk_arr = kv->d_len; fp.sk_add = 1;
+            fp.nsplit = nsplit; fp.part_ml = part; fp.part_o = part + (size_t)M * NKV * nsplit * (NH / NKV) * 2;
+            fp.qkv_part = pbuf; fp.qkv_splits = s_qkv; fp.qkv_ld = QKV; fp.rope_cos = cosT; fp.rope_sin = sinT;
+            rope_folded = decode_attn_fold_supported(fp, HD);
+        }
+        if (!rope_folded)
+            hipLaunchKernelGGL(rope_split_kernel, dim3(M, NKV), dim3(128), 0, st, qkv, cosT, sinT, q, kc, vc, 0, 0,
+                               decode ? d_seqs : d_row_seq, decode ? kv->d_len : nullptr, decode ? nullptr : d_row_pos, kv->max_tokens,
+                               (const float*)(sliced ? pbuf : nullptr), s_qkv);
         if (last_rows_only && l + 1 == c->d.llm_layers) {
             ap.q_bs = 0; ap.q_rs = D; ap.q_hs = HD; ap.o_bs = 0; ap.o_rs = D; ap.o_hs = HD;
             ap.H = NH; ap.kv_group = NH / NKV; ap.B = n_pages; ap.seg = d_seg_last; ap.Sq = 32;
@@ -473,6 +483,7 @@ int run_layers(cr_ctx* c, cr_kv* kv, bf16* x, int M, bool decode, const std::vec
             ap.B = M; ap.H = NKV; ap.Sq = NH / NKV; ap.Sk = 0; ap.kv_group = 1; ap.q_pos0 = 0;
             ap.seq_map = d_seqs; ap.sk_arr = kv->d_len; ap.sk_add = 1;
             ap.nsplit = nsplit; ap.part_ml = part; ap.part_o = part + (size_t)M * NKV * nsplit * (NH / NKV) * 2;
+            if (rope_folded) { ap.qkv_part = pbuf; ap.qkv_splits = s_qkv; ap.qkv_ld = QKV; ap.rope_cos = cosT; ap.rope_sin = sinT; }
             if (launch_flash_attn_split(ap, HD, st) != CR_OK) return cr_fail(CR_ERR_HIP, "decode attention launch failed");
         }
         if (sliced) {

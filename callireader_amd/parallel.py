@@ -119,7 +119,7 @@ MI355X_COST = {
     # one decode step of n rows at ~3 200 cached tokens per row (weights 14.7 GB once + 131 KB of KV per row and cached token): linear between the points
     'decode_ms': {1: 2.97, 2: 3.11, 4: 3.30, 8: 3.88, 12: 4.28, 16: 4.58, 24: 5.65, 32: 6.28, 64: 8.86},
     'decode_ctx_tokens': 3228,            # the context the table was measured at (3 164-token prompt + half of 128 new tokens) ...
-    'decode_ms_per_row_token': 2.4e-5,    # ... and what a row's step costs per cached token more or less (131 KB at ~5.5 TB/s)
+    'decode_ms_per_row_token': 2.2e-5,    # ... and what a row's step costs per cached token more or less (131 KB at the ~6 TB/s the decode attention streams at)
     # a visual-stage call runs in chunks of <= 255 tiles (csrc/vision.hip: next_chunk); every chunk STARTED costs this on top of its tiles (24 layers x 7 launches
     # of cold start and tail, the weights' first read): ragged shards and pages with few tiles pay it for little work (round 5: "the odd chunks cost ~3 ms of 620")
     'chunk_tiles': 255, 'chunk_ms': 1.5,
@@ -130,7 +130,7 @@ MI355X_COST = {
 MI355X_COST_FP8 = {
     'tile_ms': 0.572, 'char_tile_ms': 0.572, 'prefill_ms_per_token': 0.00713,
     'decode_ms': {1: 2.2, 8: 3.04, 16: 3.54, 32: 4.75, 64: 7.97},
-    'decode_ctx_tokens': 3228, 'decode_ms_per_row_token': 2.4e-5,      # (the KV cache stays bf16)
+    'decode_ctx_tokens': 3228, 'decode_ms_per_row_token': 2.2e-5,      # (the KV cache stays bf16)
     'chunk_tiles': 255, 'chunk_ms': 1.2, **ALLGATHER_COST,
 }
 
@@ -328,13 +328,13 @@ def measure_cost(model, group=None, seed=0):
     tile_ms, char_ms = (tp1 - tp0) / (n1 - n0), (tc1 - tc0) / (n1 - n0)
     chunk_ms = max(0.5 * ((tp0 - n0 * tile_ms) + (tc0 - n0 * char_ms)), 0.0)
     del px
-    S = 2048
+    S, NP = 2048, 4                                    # four prompts in one prefill batch, as the page owners prefill (16 pages per batch at full size)
     emb = (torch.randn(S, dims.llm_hidden, generator=torch.Generator().manual_seed(seed)) * 0.02).to(torch.bfloat16).to(dev)
     rows = [1, 8, 16, 64]
     ctx = 64
     kv = eng.kv_alloc(max(rows), S + 64)
     try:
-        t_pre = timed(lambda: (kv.reset(0), eng.prefill(kv, 0, emb)))
+        t_pre = timed(lambda: (kv.reset(), eng.prefill_batch(kv, list(range(NP)), [emb] * NP))) / NP
         kv.reset()
         eng.prefill_batch(kv, list(range(max(rows))), [emb[:ctx]] * max(rows))
         dec = {}
@@ -343,7 +343,7 @@ def measure_cost(model, group=None, seed=0):
             dec[r] = timed(lambda: eng.decode(kv, live), reps=6)
     finally:
         kv.free()
-    per_tok = base.get('decode_ms_per_row_token', 2.4e-5)
+    per_tok = base.get('decode_ms_per_row_token', 2.2e-5)
     cost = dict(base, tile_ms=round(tile_ms, 4), char_tile_ms=round(char_ms, 4), chunk_ms=round(chunk_ms, 3), prefill_ms_per_token=round(t_pre / S, 5),
                 decode_ms={r: round(t, 3) for r, t in dec.items()}, decode_ctx_tokens=ctx + 4, decode_ms_per_row_token=per_tok, measured=True)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
