@@ -145,6 +145,7 @@ int cr_create(int device, const cr_model_desc* desc, cr_ctx** out) {
     { const char* e = getenv("CR_DECODE_GRAPH"); if (e) c->decode_graph = atoi(e) != 0; }
     { const char* e = getenv("CR_DECODE_FUSED"); if (e) c->fused_decode = atoi(e) != 0; }
     { const char* e = getenv("CR_DECODE_FOLD_ROPE"); if (e) c->fold_rope = atoi(e) != 0; }
+    { const char* e = getenv("CR_PERCEIVER_ATTN_V1"); if (e) c->perceiver_v1 = atoi(e) != 0; }
     { const char* e = getenv("CR_PREFILL_LAST_ROWS"); if (e) c->prefill_last_rows = atoi(e) != 0; }
     c->scratch_bytes = 1 << 20;
     if (hipMalloc((void**)&c->scratch, c->scratch_bytes) != hipSuccess) { delete c; return cr_fail(CR_ERR_NOMEM, "scratch"); }

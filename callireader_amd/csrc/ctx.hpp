@@ -36,6 +36,7 @@ struct cr_ctx {
     bool fused_decode = true;           // decode batches of <= DECODE_FUSED_MAX_ROWS (8) rows take gemm_decode.hip (six launches per layer, the same bits); CR_DECODE_FUSED=0: the separate kernels
     bool prefill_last_rows = true;      // prefill: the final decoder layer's attention / wo / w1|w3 / w2 on each page's last row only (bit-identical; CR_PREFILL_LAST_ROWS=0: all rows)
     bool no_sliced_decode = false;      // CR_NO_SLICED_DECODE=1: decode through the one-tile weight-streaming GEMMs (A/B aid)
+    bool perceiver_v1 = false;          // CR_PERCEIVER_ATTN_V1=1 at cr_create: round 1's perceiver attention kernel (the bit-for-bit yardstick of the current one)
     bool fold_rope = true;              // 9..64-row decode: RoPE + split + the new token's cache row inside the attention kernel (attention_decode.hip FOLD; bit-identical); CR_DECODE_FOLD_ROPE=0 at cr_create: rope_split_kernel as its own launch
     std::unordered_map<std::string, DevTensor> w;
     // workspace

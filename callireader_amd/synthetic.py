@@ -263,6 +263,13 @@ PEAKED = dict(branch_shift=9, a=0.25, runner=0.7, back=1.2, noise_std=0.002, len
               back_at=(9, 17, 26, 34, 45, 58, 66), back_hop=4, runner_shift=40503, eos=92542, start_b=2000)
 
 
+# The LONG streams (round-5 verdict, item 5): the same construction at reduced depth (2 layers, full width, full vocabulary) with a walk A that does not reach EOS
+# within the API's default max_new_tokens = 1024 (inference.py:92-96) and a walk B whose EOS override comes as its 85th token (85 = 5 mod 16: the engine looks for
+# EOS every 16 steps).  A third stream enters walk A `long_c_entry` tokens in and reaches A's EOS as its (len_a - long_c_entry)-th token.
+PEAKED_LONG = dict(PEAKED, len_a=1400, len_b=85, back_at=(9, 17, 26, 34, 45, 58, 66, 77), long_c_entry=1003, llm_layers=2, start_a=3000,
+                   prompt_lens=(333, 77, 200))
+
+
 def peaked_plan(vocab, start_a, seed=0, cfg=PEAKED):
     """The walk tables of the peaked checkpoint.  Returns dict(t1, t2 (LongTensor[vocab]), overrides [(v, u, strength)],
     chain_a, chain_b (ids each walk is BUILT to generate, EOS included), loop_b (what chain B's prompt generates without a

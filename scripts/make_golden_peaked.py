@@ -22,6 +22,11 @@ and the walk the checkpoint was built to produce (so a CPU test can check golden
 
   python scripts/make_golden_peaked.py --calibrate     short prompt, a few steps: prints logits / margins (5 min)
   python scripts/make_golden_peaked.py                 the golden file
+  python scripts/make_golden_peaked.py --long          tests/golden/peaked_long.npz (round 6): the LONG streams -- synthetic.PEAKED_LONG at 2 layers, full width,
+                                                       full vocabulary: LA 1 024 free-running tokens (the API's default max_new_tokens, no EOS on the way), LB
+                                                       EOS as its 85th token (85 = 5 mod 16) with eight steps the penalty decides, LC enters walk A 1 003 tokens
+                                                       in and stops on A's EOS as its 397th token; all three at repetition_penalty 1.5 (chat_ocr's default,
+                                                       modeling_internvl_chat.py:652), text-only prompts of 333 / 77 / 200 ids.  ids + margins only (< 100 KB).
 """
 import argparse
 import json
@@ -40,16 +45,19 @@ from make_golden import install_stubs, REF, OUT  # noqa: E402
 SEED = 0
 
 
-def build_peaked_llm(cfg, start_a):
-    """As make_golden_full_depth.build_llm, filled from synthetic.iter_peaked_llm."""
+def build_peaked_llm(cfg, start_a, dims=None, pcfg=None):
+    """As make_golden_full_depth.build_llm, filled from synthetic.iter_peaked_llm (dims / pcfg: the reduced-depth LONG variant)."""
     import copy
     from transformers.initialization import no_init_weights
     from InternVL.configuration_internlm2 import InternLM2Config
     from InternVL.modeling_internlm2 import InternLM2ForCausalLM
     from callireader_amd.config import ModelDims
     from callireader_amd import synthetic
+    dims = dims or ModelDims.full()
+    pcfg = pcfg or synthetic.PEAKED
     lcfg = copy.deepcopy(cfg['llm_config'])
     lcfg['attn_implementation'] = 'eager'
+    lcfg['num_hidden_layers'] = dims.llm_layers
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)
     try:
@@ -61,7 +69,7 @@ def build_peaked_llm(cfg, start_a):
     params = dict(llm.named_parameters())
     seen = set()
     with torch.no_grad():
-        for k, v in synthetic.iter_peaked_llm(ModelDims.full(), start_a, seed=SEED):
+        for k, v in synthetic.iter_peaked_llm(dims, start_a, seed=SEED, cfg=pcfg):
             name = k[len('language_model.'):]
             params[name].copy_(v)
             seen.add(name)
@@ -71,7 +79,7 @@ def build_peaked_llm(cfg, start_a):
     return llm
 
 
-def run_stream(llm, emb, penalty, max_new_tokens, eos, tag, t0, past0=None):
+def run_stream(llm, emb, penalty, max_new_tokens, eos, tag, t0, past0=None, keep_top=True, quiet=False):
     """The greedy loop of transformers 4.45.2 `_sample` for these arguments, with the installed release's own processor and
     stopping criteria.  Returns (record dict, (logits, past) of the prefill so that a second stream can start from it)."""
     from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
@@ -94,24 +102,77 @@ def run_stream(llm, emb, penalty, max_new_tokens, eos, tag, t0, past0=None):
             toks.append(nxt)
             margins.append(float(top.values[0] - top.values[1]))
             raw_gap.append(float(row[0, nxt] - raw.values[0]))            # < 0 where the penalty overruled the raw arg-max
-            top_i.append(raw.indices.numpy().astype(np.int64)); top_v.append(raw.values.numpy())
+            if keep_top:
+                top_i.append(raw.indices.numpy().astype(np.int64)); top_v.append(raw.values.numpy())
             ids = torch.cat([ids, torch.tensor([[nxt]])], dim=1)
-            print(f'[{time.time() - t0:.0f}s] {tag} token {len(toks)}: id {nxt}, margin {margins[-1]:.3f}, raw top {float(raw.values[0]):.2f}'
-                  f'{" (penalty decided)" if raw_gap[-1] < 0 else ""}', flush=True)
+            if not quiet or len(toks) % 64 == 0 or raw_gap[-1] < 0:
+                print(f'[{time.time() - t0:.0f}s] {tag} token {len(toks)}: id {nxt}, margin {margins[-1]:.3f}, raw top {float(raw.values[0]):.2f}'
+                      f'{" (penalty decided)" if raw_gap[-1] < 0 else ""}', flush=True)
             if bool(stop_eos(ids, None)[0]) or bool(stop_len(ids, None)[0]):
                 break
             pos = torch.tensor([[past[0][0].shape[2]]])
             o = llm(input_ids=torch.tensor([[nxt]]), past_key_values=past, position_ids=pos, use_cache=True, return_dict=True)
             row, past = o.logits[:, -1, :].float(), o.past_key_values
-    rec = {f'{tag}.ids': np.array(toks, dtype=np.int64), f'{tag}.margin': np.array(margins), f'{tag}.raw_gap': np.array(raw_gap),
-           f'{tag}.top16_ids': np.stack(top_i), f'{tag}.top16_logits': np.stack(top_v)}
+    rec = {f'{tag}.ids': np.array(toks, dtype=np.int64), f'{tag}.margin': np.array(margins), f'{tag}.raw_gap': np.array(raw_gap)}
+    if keep_top:
+        rec.update({f'{tag}.top16_ids': np.stack(top_i), f'{tag}.top16_logits': np.stack(top_v)})
     return rec, past0
+
+
+def long_prompts(cfg, plan):
+    """Text-only prompts of the LONG streams: seeded ids, the last one the walk's entry token (a CPU draw the GPU test repeats)."""
+    g = torch.Generator().manual_seed(20261003)
+    la, lb, lc = cfg['prompt_lens']
+    entry_c = plan['chain_a'][cfg['long_c_entry'] - 1]            # the token after which walk A continues with chain_a[long_c_entry:]
+    out = []
+    for n, last in ((la, cfg['start_a']), (lb, plan['start_b']), (lc, entry_c)):
+        ids = torch.randint(100, 60000, (n,), generator=g)
+        ids[-1] = last
+        out.append(ids)
+    return out
+
+
+def main_long():
+    install_stubs()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    from callireader_amd.config import ModelDims
+    from callireader_amd import synthetic
+    cfg = json.load(open(os.path.join(REF, 'InternVL', 'config.json')))
+    P = synthetic.PEAKED_LONG
+    dims = ModelDims.reduced(llm_layers=P['llm_layers'])
+    plan = synthetic.peaked_plan(dims.vocab, P['start_a'], SEED, P)
+    t0 = time.time()
+    llm = build_peaked_llm(cfg, P['start_a'], dims, P)
+    print(f'[{time.time() - t0:.0f}s] peaked LLM ({dims.llm_layers} layers) built', flush=True)
+    prompts = long_prompts(P, plan)
+    gold = {}
+    expect = {'LA': plan['chain_a'][:1024], 'LB': plan['chain_b'], 'LC': plan['chain_a'][P['long_c_entry']:]}
+    for tag, ids in zip(('LA', 'LB', 'LC'), prompts):
+        with torch.no_grad():
+            emb = llm.get_input_embeddings()(ids.reshape(1, -1))              # text only: generate_ocr's :1107 branch
+        rec, _ = run_stream(llm, emb, 1.5, 1024, P['eos'], tag, t0, keep_top=False, quiet=True)
+        got = rec[f'{tag}.ids'].tolist()
+        print(f'{tag}: {len(got)} tokens, equal to the built walk: {got == expect[tag]}, margin min {rec[tag + ".margin"].min():.3f}', flush=True)
+        gold[f'{tag}.ids'] = rec[f'{tag}.ids'].astype(np.int32)
+        gold[f'{tag}.margin'] = rec[f'{tag}.margin'].astype(np.float16)
+        gold[f'{tag}.penalty_decided'] = (rec[f'{tag}.raw_gap'] < 0).nonzero()[0].astype(np.int32)
+        gold[f'{tag}.prompt'] = ids.numpy().astype(np.int32)
+    meta = {'seed': SEED, 'peaked_long': {k: (list(v) if isinstance(v, tuple) else v) for k, v in P.items()}, 'penalty': 1.5, 'max_new_tokens': 1024,
+            'torch': torch.__version__, 'transformers': __import__('transformers').__version__}
+    gold['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, 'peaked_long.npz')
+    np.savez_compressed(path, **gold)
+    print('wrote', path, os.path.getsize(path), 'bytes', f'{time.time() - t0:.0f}s')
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--calibrate', action='store_true')
+    ap.add_argument('--long', action='store_true')
     args = ap.parse_args()
+    if args.long:
+        return main_long()
     install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())

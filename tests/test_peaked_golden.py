@@ -73,3 +73,23 @@ def test_oracle_loop_pieces_reproduce_the_reference_picks():
             out.append(nxt)
             stop = nxt == synthetic.PEAKED['eos'] or len(out) >= cfg['max_new_tokens']
             assert stop == (t == len(ids) - 1), (tag, t)
+
+
+def test_long_streams_are_the_built_walks_with_wide_margins():
+    """tests/golden/peaked_long.npz (make_golden_peaked.py --long): the reference walked exactly what synthetic.PEAKED_LONG builds, for 1 024 / 85 / 397 tokens."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'peaked_long.npz'))
+    meta = json.loads(bytes(g['meta']).decode())
+    P = synthetic.PEAKED_LONG
+    assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in P.items()} == meta['peaked_long'], \
+        'synthetic.PEAKED_LONG changed: regenerate tests/golden/peaked_long.npz (scripts/make_golden_peaked.py --long)'
+    plan = synthetic.peaked_plan(ModelDims.full().vocab, P['start_a'], meta['seed'], P)
+    la, lb, lc = (g[f'{t}.ids'].tolist() for t in ('LA', 'LB', 'LC'))
+    assert la == plan['chain_a'][:1024] and len(la) == meta['max_new_tokens'] == 1024 and P['eos'] not in la          # stopped by MaxLengthCriteria
+    assert lb == plan['chain_b'] and len(lb) == 85 and len(lb) % 16 == 5 and lb[-1] == P['eos']
+    assert lc == plan['chain_a'][P['long_c_entry']:] and len(lc) == 397 and lc[-1] == P['eos']
+    assert g['LB.penalty_decided'].tolist() == list(P['back_at']) and g['LA.penalty_decided'].size == 0 and g['LC.penalty_decided'].size == 0
+    for t in ('LA', 'LB', 'LC'):
+        assert float(g[f'{t}.margin'].min()) >= 2.0, (t, float(g[f'{t}.margin'].min()))
+        assert g[f'{t}.prompt'].shape[0] == P['prompt_lens'][('LA', 'LB', 'LC').index(t)]
+    assert int(g['LA.prompt'][-1]) == P['start_a'] and int(g['LB.prompt'][-1]) == plan['start_b'] and int(g['LC.prompt'][-1]) == plan['chain_a'][P['long_c_entry'] - 1]
+    assert os.path.getsize(os.path.join(ROOT, 'tests', 'golden', 'peaked_long.npz')) < 100 * 1024
