@@ -129,7 +129,9 @@ def main():
     n_pages, mine, ct_lo, ct_hi = wl['n_pages'], wl['mine'], wl['ct_lo'], wl['ct_hi']
     P = wl['pages_per_gpu']                              # pages this rank owns per step (round-robin; = --pages with weak scaling)
     S_page = PAGE_TILES * 256 + CHAR_TILES * 3 + TEXT_TOKENS
-    model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=S_page + NEW_TOKENS + 128, max_pages=P)
+    # (room for the ragged batch of strong_share.balanced_ragged: pages of up to 13 page tiles and 250 character tiles; a longer cache changes no step's work)
+    longest_prompt = max(S_page, 13 * 256 + 250 * 3 + TEXT_TOKENS) if (world == 1 and not args.no_strong_share and not args.no_ragged) else S_page
+    model = InternVLChatModel.from_synthetic(dims, seed=0, device=local_rank, max_tokens=longest_prompt + NEW_TOKENS + 128, max_pages=P)
     model.img_context_token_id = IMG_CONTEXT_TOKEN_ID
     eng = model.engine
 

@@ -29,9 +29,9 @@ def sources():
 
 
 def source_hash():
-    """First 16 hex digits of sha256 over every .hip / .hpp under csrc/ and the ABI header (names and contents, sorted)."""
+    """First 16 hex digits of sha256 over every .hip / .hpp / .inc under csrc/ and the ABI header (names and contents, sorted)."""
     h = hashlib.sha256()
-    deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')) + [HEADER]
+    deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.inc'))) + [HEADER]
     for d in deps:
         h.update(os.path.basename(d).encode() + b'\0')
         with open(d, 'rb') as f:

@@ -74,19 +74,8 @@ constexpr int LDS_MAIN2 = 2 * KBUF;               // 131072
 constexpr int LDS_BYTES2 = LDS_MAIN2 + 8 * 4096;  // + one 16x64 fp32 slice per wave = 163840 (all of the CU's LDS)
 
 #define WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-#ifdef CR_BREAK_WAIT    // diagnostic (scripts/hazard_teeth.py): NO counted wait in the main loop and none after the cold-start fills
-#define WAIT_VM8() asm volatile("s_waitcnt vmcnt(63)" ::: "memory")
-#define WAIT_COLD() asm volatile("s_waitcnt vmcnt(63)" ::: "memory")
-#else
-#define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#define WAIT_COLD() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
+#include "gemm256_diag.inc"      // WAIT_VM8 / WAIT_COLD / CR_STORE_OUT / KI_VALU and the GM256_* hooks: the product's definitions, and the diagnostic builds' (diag.hpp is the door)
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#ifdef CR_KO_STORE      // diagnostic build: the plain-store epilogue keeps its values alive but sends nothing (wrong results)
-#define CR_STORE_OUT(v, ptr) asm volatile("" ::"v"(v), "v"(ptr))
-#else
-#define CR_STORE_OUT(v, ptr) __builtin_nontemporal_store(v, ptr)
-#endif
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)   /* lgkmcnt(0); the builtin (unlike inline asm) is seen by the compiler's own wait insertion */
 
 // ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------------------------
@@ -518,11 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     auto tile_origin = [&](int orig, int& m0, int& n0) {
         const int xcd = orig & 7, q = ntiles >> 3, r = ntiles & 7;
         const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-#ifdef CR_TILE_GM       // diagnostic (scripts/traffic_clock.py): another super-group height -- right results, other operand traffic (1: row-major tile order)
-        constexpr int GM = CR_TILE_GM;
-#else
-        constexpr int GM = 8;
-#endif
+        constexpr int GM = GM256_TILE_GM;                     // 8 (gemm256_diag.inc: CR_TILE_GM for scripts/traffic_clock.py)
         const int per_group = GM * ntn;
         const int grp = pid / per_group;
         const int first_m = grp * GM;
@@ -556,47 +541,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             const int brow = n0 + (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + srow;
             qA[h] = (uint32_t)(((int64_t)min(arow, p.M - 1) * p.lda + schunk * 8) * 2);
             qB[h] = (uint32_t)(((int64_t)min(brow, p.N - 1) * p.ldw + schunk * 8) * 2);
-#ifdef CR_KO_WCONTIG      // knock-out (wrong results, cost structure only): the weight panel read as contiguous KiB blocks, what a pre-tiled copy would allow
-            qB[h] = (uint32_t)((int64_t)n0 * p.ldw * 2 + (h * 8 + wave) * 2048 + (lane & 63) * 16);
-#endif
-#ifdef CR_KO_AROWS        // knock-out: an activation instruction reads 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B
-            qA[h] = (uint32_t)(((int64_t)min(arow - srow + (lane >> 3), p.M - 1) * p.lda + (lane & 7) * 8) * 2);
-#endif
+            GM256_DIAG_STAGE_OFFSETS(h)
         }
     };
     auto dma = [&](const bf16* base, uint32_t o, int kt, int buf, int u) {
         char* dst = smem + buf * KBUF + u * UNIT + (2 * wave) * 1024;
-#ifdef CR_POISON
-        // Hazard screen (diagnostic build): the two sub-tiles this wave is about to refill are overwritten with bf16 NaNs
-        // first.  By the schedule's WAR rule nobody may still read them, by its RAW rule nobody reads them again before the new bytes have landed: a
-        // read that breaks either rule now returns NaNs and the integer-exact tests fail instead of passing by luck (tests/test_gpu_ops.py runs them
-        // on this build).
-        {
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_p;
-            const u32x4_p nan4 = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
-            *(u32x4_p*)(dst + lane * 16) = nan4;
-            *(u32x4_p*)(dst + 1024 + lane * 16) = nan4;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-#endif
+        GM256_DIAG_POISON(dst)
         const char* src = (const char*)base + (int64_t)kt * (BK2 * 2);
-#if defined(CR_KO_WCONTIG) || defined(CR_KO_AROWS)
-        {
-            bool alt = false;
-            int64_t second = 0;
-#ifdef CR_KO_WCONTIG
-            if (base == p.W) { alt = true; src = (const char*)base + (int64_t)kt * (256 * BK2 * 2); second = 1024; }
-#endif
-#ifdef CR_KO_AROWS
-            if (base == p.A) { alt = true; second = (int64_t)8 * p.lda * 2; }
-#endif
-            if (alt) {
-                __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(CR_GLB(src + o + second), CR_LDS(dst + 1024), 16, 0, 0);
-                return;
-            }
-        }
-#endif
+        GM256_DIAG_ALT_DMA(base, src, o, dst, kt)
         __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst), 16, 0, 0);
         // the instruction's immediate offset is added to the global AND to the LDS address: M0 is set 64 short
         __builtin_amdgcn_global_load_lds(CR_GLB(src + o), CR_LDS(dst + 1024 - 64), 16, 64, 0);
@@ -630,11 +582,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // a phase = a memory slot (fragment reads of this phase, one unit's two DMA pieces, the counted wait) and a
     // matrix slot (16 MFMAs), each closed by s_barrier.  Waves 4..7 run one slot behind waves 0..3, so on every
     // SIMD one wave's matrix slot runs beside its partner's memory slot.
-#ifdef CR_KI_VALU   // knock-in diagnostic (HISTORY.md): CR_KI_VALU independent vector instructions in every memory slot -- is vector issue free there?
-#define KI_VALU() _Pragma("unroll") for (int q_ = 0; q_ < CR_KI_VALU; q_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(ki[q_ & 3]))
-#else
-#define KI_VALU()
-#endif
 #define MEM_SLOT_B(READS, DMA, WAIT)      /* 32-MFMA schedule: the reads are retired in front of the slot's barrier */ \
     READS;                                                                                      \
     DMA;                                                                                        \
@@ -686,9 +633,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_barrier();
 
-#ifdef CR_KI_VALU
-    float ki[4] = {1.f, 1.f, 1.f, 1.f};
-#endif
+    GM256_DIAG_KI_DECL
     int t_cur = blockIdx.x;
     if (t_cur >= ntiles) return;
     int m0, n0;
@@ -726,12 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             const bf16* src = (lane < 32 || EPI != EPI_LS_RES) ? (p.bias ? p.bias : p.scale) : p.scale;
             __builtin_amdgcn_global_load_lds(CR_GLB(src + n0 + wn * 64 + (lane & 31) * 2), CR_LDS(stg), 4, 0, 0);
         }
-#ifdef CR_DIAG_STAMPS
-        uint64_t* dbg = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + (t_cur / gridDim.x)) * 4;
-        const bool stamp = p.scale && (wave & 3) == 0 && lane == 0 && (t_cur / gridDim.x) < 31;      // row 31 holds the workgroup's real-time stamps
-        if (stamp) dbg[0] = __builtin_amdgcn_s_memtime();
-        if (stamp && t_cur == (int)blockIdx.x) { uint64_t* d31 = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + 31) * 4; d31[0] = __builtin_amdgcn_s_memrealtime(); d31[2] = __builtin_amdgcn_s_memtime(); }
-#endif
+        GM256_STAMP_BEGIN
         if (wm) __builtin_amdgcn_s_barrier();                  // waves 4..7 start one slot late
 
         if (BIG) {
@@ -795,26 +735,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             MFMA_SLOT(1, 0);
         }
         }
-#ifdef CR_DIAG_STAMPS
-        if (stamp) dbg[1] = __builtin_amdgcn_s_memtime();
-#endif
+        GM256_STAMP(1)
         if (!wm) __builtin_amdgcn_s_barrier();                 // waves 0..3 wait out the partners' last matrix slot
         WAIT_VM0();
-#ifdef CR_DIAG_STAMPS
-        if (stamp) dbg[2] = __builtin_amdgcn_s_memtime();
-#endif       // the look-ahead (K-tile 0 and U0, U1 of K-tile 1 of the next tile) has landed: slots 1..4 rely on it
+        GM256_STAMP(2)       // the look-ahead (K-tile 0 and U0, U1 of K-tile 1 of the next tile) has landed: slots 1..4 rely on it
 
         // ---- epilogue: eight 16-row slices per wave through its private 4 KiB (the K buffers stay untouched) ----
-#ifdef CR_KO_EPI         // diagnostic build: no epilogue at all (wrong results): what hiding it completely could buy
-        _Pragma("unroll") for (int i = 0; i < 8; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
-#else
-        if (EPI == EPI_GELU_Q8) epilogue_gelu_q8(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
-        else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane, lut, pre_ok ? stg : nullptr);
-#endif
-#ifdef CR_DIAG_STAMPS
-        if (stamp) dbg[3] = __builtin_amdgcn_s_memtime();
-        if (stamp && !has_next) { uint64_t* d31 = (uint64_t*)p.scale + ((int64_t)(blockIdx.x * 2 + wm) * 32 + 31) * 4; d31[1] = __builtin_amdgcn_s_memrealtime(); d31[3] = __builtin_amdgcn_s_memtime(); }
-#endif
+        GM256_EPILOGUE(if (EPI == EPI_GELU_Q8) epilogue_gelu_q8(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane);
+                       else epilogue_tile<EPI, F8>(p, acc, stg, m0 + wm * 128, n0 + wn * 64, lane, lut, pre_ok ? stg : nullptr);)
+        GM256_STAMP_END
         if (!has_next) break;
         t_cur = t_next;
         tile_origin(t_cur, m0, n0);
