@@ -88,7 +88,7 @@ def main():
     ap.add_argument('--share-steps', type=int, default=2, help='timed steps of strong_share')
     ap.add_argument('--fp8-extras', action='store_true', help='also time the batched decode on e4m3 weight copies alone (fp8_decode) and compare its first picks with the bf16 decode')
     ap.add_argument('--no-api', action='store_true', help='N = 1: skip the api_level block (the same batch from JPEG files through chat_ocr_stream / folder_rec to strings)')
-    ap.add_argument('--api-batches', type=int, default=4, help='batches of --pages pages the api_level block streams')
+    ap.add_argument('--api-batches', type=int, default=6, help='batches of --pages pages the api_level block streams')
     ap.add_argument('--no-pipeline', action='store_true', help='one batch at a time (the decode of a batch does not run beside the visual stage of the next)')
     args = ap.parse_args()
     plan.NEW_TOKENS = NEW_TOKENS = args.new_tokens
@@ -395,6 +395,12 @@ def main():
             try:
                 result['api_level'] = api_level(model, ROOT, pages=P, batches=args.api_batches, new_tokens=NEW_TOKENS, folder_pages=2 * P,
                                                 headline_ms_per_step=ms_per_step, headline_pages=n_pages)
+                # the synthetic step again, right after the API run (same thermal state): does the box still run the one-batch-at-a-time step in the time it took before?
+                step(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step(); torch.cuda.synchronize()
+                result['api_level']['synthetic_step_one_batch_at_a_time_ms'] = {'before_the_api_run': round(seq_ms, 1) if seq_ms else None,
+                                                                              'after_the_api_run': round((time.perf_counter() - t0) * 1e3, 1)}
             except Exception as e:                      # never at the cost of the line
                 import traceback
                 traceback.print_exc()

