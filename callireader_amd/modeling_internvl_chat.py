@@ -764,7 +764,7 @@ class PagePipeline:
         from .engine import Engine
         self.m, self.eng = model, model.engine
         self.max_new_tokens, self.eos, self.penalty = max_new_tokens, eos_token_id, repetition_penalty
-        self.check_every, self.prefill_batch = check_every, prefill_batch
+        self.check_every, self.prefill_batch = int(os.environ.get('CR_PIPE_CHECK_EVERY', check_every)), prefill_batch      # (env: development aid, how often the decode thread looks for EOS)
         self.dec = Engine(self.eng.dims, device=self.eng.device.index, max_pos=self.eng.max_pos)
         self.dec.share_weights_from(self.eng)
         # a stream of another priority level also lands on another hardware queue than the caller's (two streams of one level may share one)
