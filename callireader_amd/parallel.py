@@ -328,7 +328,7 @@ def measure_cost(model, group=None, seed=0):
     tile_ms, char_ms = (tp1 - tp0) / (n1 - n0), (tc1 - tc0) / (n1 - n0)
     chunk_ms = max(0.5 * ((tp0 - n0 * tile_ms) + (tc0 - n0 * char_ms)), 0.0)
     del px
-    S, NP = 2048, 4                                    # four prompts in one prefill batch, as the page owners prefill (16 pages per batch at full size)
+    S, NP = max(min(2048, (eng.max_pos - 64) // 64 * 64), 128), 4      # four prompts in one prefill batch, as the page owners prefill (16 pages per batch at full size); within the model's RoPE table
     emb = (torch.randn(S, dims.llm_hidden, generator=torch.Generator().manual_seed(seed)) * 0.02).to(torch.bfloat16).to(dev)
     rows = [1, 8, 16, 64]
     ctx = 64

@@ -69,6 +69,14 @@ rag_pages_pt = [page_px[p * PT:p * PT + rag_pt[p]] for p in range(n_pages)]
 rag_pages_ct = [char_px[p * CT:p * CT + rag_ct[p]] for p in range(n_pages)]
 rag_ids = [torch.cat([torch.arange(50 + p, 60 + p), torch.full((rag_pt[p] * 256,), IMG), torch.full((rag_ct[p] * 3,), REF), torch.arange(7)]) for p in range(n_pages)]
 rag_out = sharded_generate(m, rag_pages_pt, rag_pages_ct, rag_ids, img_id=IMG, ref_id=REF, max_new_tokens=NEW, eos_token_id=None)
+# (d) round 6: the plan made under stage costs MEASURED on the GPU at hand (parallel.measure_cost: every rank measures, rank 0's numbers are broadcast so that all
+# ranks compute the same plan), and a batch of pages WITHOUT any character tile (nothing to gather: no zero-byte collective)
+meas_out = sharded_generate(m, pages_pt, pages_ct, ids, img_id=IMG, ref_id=REF, max_new_tokens=NEW, eos_token_id=None, cost='measure')
+cost_used = m._measured_cost
+costs = [None] * world
+dist.all_gather_object(costs, {k: cost_used[k] for k in ('tile_ms', 'char_tile_ms', 'chunk_ms', 'prefill_ms_per_token', 'decode_ms')})
+nochar_ids = [torch.cat([torch.arange(50 + p, 60 + p), torch.full((PT * 256,), IMG), torch.arange(7)]) for p in range(n_pages)]
+nochar_out = sharded_generate(m, pages_pt, [char_px[:0]] * n_pages, nochar_ids, img_id=IMG, ref_id=REF, max_new_tokens=NEW, eos_token_id=None)
 gathered = [None] * world
 dist.all_gather_object(gathered, outs)
 if rank == 0:
@@ -88,6 +96,11 @@ if rank == 0:
         rag_embeds.append(m.engine.embed_splice(rag_ids[p].cuda(), v, ps.reshape(-1, 3, dims.llm_hidden), img_id=IMG, ref_id=REF))
     rag_single = m.generate_pages(rag_embeds, max_new_tokens=NEW, eos_token_id=None)
     ok = ok and sorted(rag_out) == list(range(n_pages)) and all(rag_out[p] == rag_single[p] for p in range(n_pages))
+    ok = ok and sorted(meas_out) == list(range(n_pages)) and all(meas_out[p] == single[p] for p in range(n_pages))
+    ok = ok and all(c == costs[0] for c in costs) and cost_used.get('measured') is True                 # one table on every rank: rank 0's
+    nochar_embeds = [m.engine.embed_splice(nochar_ids[p].cuda(), v1[p * PT:(p + 1) * PT], None, img_id=IMG, ref_id=REF) for p in range(n_pages)]
+    nochar_single = m.generate_pages(nochar_embeds, max_new_tokens=NEW, eos_token_id=None)
+    ok = ok and sorted(nochar_out) == list(range(n_pages)) and all(nochar_out[p] == nochar_single[p] for p in range(n_pages))
     print('DIST_CHECK', 'OK' if ok else 'MISMATCH', merged, single, flush=True)
     out = os.environ.get('CR_DIST_JSON')
     if out:
