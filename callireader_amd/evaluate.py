@@ -330,7 +330,7 @@ def main(argv=None):
     parser.add_argument('--repetition_penalty', type=float, default=1.0)
     parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
     parser.add_argument('--params', type=str, default='./params')
-    parser.add_argument('--batch_pages', type=int, default=16, help='pages sent through the engine together')
+    parser.add_argument('--batch_pages', type=int, default=64, help='pages sent through the engine together (64 = the most rows the batched decode takes, the batch the headline is measured on; 1 = page after page, as the reference)')
     parser.add_argument('--fp8_decode', action='store_true', help='BASELINE config 5: e4m3 weights for the batched decode (cr_enable_fp8_decode)')
     parser.add_argument('--fp8_mfma', type=int, nargs='?', const=1, default=0, choices=(0, 1, 2),
                         help='BASELINE config 5: e4m3 x e4m3 matrix-core linears (cr_enable_fp8_mfma): 1 = the norm-fed linears of the ViT / projector / prefill, 2 = also ViT fc2 and the prefill\'s wo / w2')
