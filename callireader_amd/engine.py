@@ -49,6 +49,7 @@ class Engine:
         self._h = h
         self._kv = []
         self.fp8_decode, self.fp8_mfma = False, 0          # mirrors of the context's options (parallel.default_cost picks the cost table by them)
+        self.weights_version = 0                           # bumped by everything after which a borrower (share_weights_from) must share again: loads, finalize, the fp8 switches
 
     def close(self):
         if getattr(self, '_h', None):
@@ -66,6 +67,7 @@ class Engine:
         t = t.detach().contiguous()
         if not name.startswith('orderformer.'):
             self.fp8_decode, self.fp8_mfma = False, 0      # cr_load_weight switches the options off with the copies they read
+        self.weights_version += 1
         shape = (C.c_int64 * t.dim())(*t.shape)
         B.check(B.lib.cr_load_weight(self._h, name.encode(), _p(t), _DT[t.dtype], shape, t.dim(),
                                      0 if t.is_cuda else 1, _stream()), f'cr_load_weight({name})')
@@ -83,6 +85,7 @@ class Engine:
 
     def finalize(self):
         B.check(B.lib.cr_finalize(self._h, _stream()), 'cr_finalize')
+        self.weights_version += 1
 
     def share_weights_from(self, other):
         """cr_share_weights: this (fresh) engine uses `other`'s finalized weights without copying them -- a second host thread can
@@ -95,6 +98,7 @@ class Engine:
         bf16 ones: half the HBM bytes per step.  Off by default: the reference computes in bf16 (include/callireader_hip.h)."""
         B.check(B.lib.cr_enable_fp8_decode(self._h, 1 if on else 0, _stream()), 'cr_enable_fp8_decode')
         self.fp8_decode = bool(on)
+        self.weights_version += 1
 
     # ---- vision ----
     def enable_fp8_mfma(self, on=True, level=1):
@@ -103,6 +107,7 @@ class Engine:
         option whose accuracy only a real checkpoint can price (evaluate.py --compare_fp8)."""
         B.check(B.lib.cr_enable_fp8_mfma(self._h, (2 if level >= 2 else 1) if on else 0, _stream()), 'cr_enable_fp8_mfma')
         self.fp8_mfma = ((2 if level >= 2 else 1) if on else 0)
+        self.weights_version += 1
 
     def _chk_pixels(self, px):
         if px.dim() != 4:

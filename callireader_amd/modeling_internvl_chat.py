@@ -562,7 +562,8 @@ class InternVLChatModel:
         if getattr(self, '_pagefeeder', None) is None:
             from .pageio import PageFeeder
             self._pagefeeder = PageFeeder(self)
-            self._tok_cache, self._tok_s = {}, 0.0
+            if getattr(self, '_tok_cache', None) is None:
+                self._tok_cache, self._tok_s = {}, 0.0
         return self._pagefeeder
 
     def _prompt_ids(self, tokenizer, q, n_tiles, n_ref, IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN):
@@ -572,6 +573,8 @@ class InternVLChatModel:
         The skeleton is tokenised once per question; the FIRST page of every skeleton is also tokenised in full and compared -- a tokenizer for which the
         shortcut does not hold keeps the full path."""
         t0 = time.perf_counter()
+        if getattr(self, '_tok_cache', None) is None:
+            self._tok_cache, self._tok_s = {}, 0.0
         ctx = IMG_CONTEXT_TOKEN * (self.num_image_token * n_tiles)
         appended = n_ref is not None and ALIGNED_TOKEN not in q
         def full():

@@ -41,6 +41,18 @@ def _decode_one(im, device):
         return None, err, time.perf_counter() - t0
 
 
+_POOL = None
+
+
+def decode_pages(images, device, workers=None):
+    """[(PIL page, pinned uint8 tensor, seconds) | (None, exception, seconds)] for a list of paths / PIL images, decoded on a module-level thread pool (callers without a
+    PageFeeder: parallel.chat_ocr_pages_sharded)."""
+    global _POOL
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1), thread_name_prefix='cr-decode')
+    return [f.result() for f in [_POOL.submit(_decode_one, im, device) for im in images]]
+
+
 class PageTiles:
     """One batch after tiles(): `ok` = indices (into the batch) of the pages that made it, `failed` = {index: exception}; page_px / char_px hold the tiles of
     the ok pages in order (n_tiles / n_chars per ok page); `ready` = event on the feeder's stream after the last tile kernel."""
@@ -55,7 +67,7 @@ class PageFeeder:
         self.io = Engine(eng.dims, device=eng.device.index, max_pos=64)       # own workspace; borrows the OrderFormer weights when there is a sorter
         self.stream = torch.cuda.Stream(device=eng.device)
         self.pool = ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1), thread_name_prefix='cr-decode')
-        self._sorter_of, self._sorter = None, None
+        self._sorter_of, self._sorter, self._shared_version = None, None, -1
         self.stats = {'pages': 0, 'decode_s': 0.0, 'decode_wait_s': 0.0, 'detect_s': 0.0, 'plan_s': 0.0, 'enqueue_s': 0.0}
 
     def close(self):
@@ -76,10 +88,12 @@ class PageFeeder:
         src = self.m.sorter
         if src is None:
             return None
-        if self._sorter_of is not src:
+        ver = self.m.engine.weights_version
+        if self._sorter_of is not src or self._shared_version != ver:      # (a reload / re-finalize / fp8 switch of the owner invalidates what a borrower holds)
             from .ordering import OrderFormer
+            self.stream.synchronize()
             self.io.share_weights_from(self.m.engine)
-            self._sorter, self._sorter_of = OrderFormer(self.io, max_nums=src.max_nums), src
+            self._sorter, self._sorter_of, self._shared_version = OrderFormer(self.io, max_nums=src.max_nums), src, ver
         return self._sorter
 
     def tiles(self, decoded, boxes_list=None, detect_model=None, use_p=True, errors='raise'):

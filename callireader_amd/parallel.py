@@ -443,10 +443,9 @@ def chat_ocr_pages_sharded(model, tokenizer, detect_model, images, question, gen
     VQ -> de-norm), one all-gather of the pseudo-token rows, and the owners of a page (plan_balanced over the pages' real sizes, or `plan`) encode its own
     tiles, splice, prefill and decode.  drop_zero is not offered here: it makes a page's prompt length depend on the VQ result of tiles another rank encodes."""
     from PIL import Image
-    import numpy as np
     from . import ordering
     from .conversation import get_conv_template
-    from .preprocess import plan_page, plan_char
+    from .preprocess import plan_page, plan_chars_array, jobs_array
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_pages = len(images)
@@ -456,70 +455,99 @@ def chat_ocr_pages_sharded(model, tokenizer, detect_model, images, question, gen
     # ---- pages and the boxes of every page, in reading order: given, or detected where the page lives and exchanged ----
     # A rank that cannot read a page or whose detector fails must not leave the others waiting in the collective (round-5 advice): every failure becomes a
     # marker, the markers are exchanged with the boxes, and EVERY rank raises the same error after the exchange.
-    pages, failures = [], {}
+    # Every rank needs every page's SIZE (tile counts and prompt lengths are the plan's inputs) but the PIXELS only of the pages it touches: sizes come from the
+    # files' headers, pixels are decoded on threads (pageio: 14.5 ms of JPEG decode per example page -- 64 pages decoded one after the other on every rank would
+    # cost more than a rank's share of the step at 8 GPUs).  Readability is checked where a page lives (rank p % world decodes it) and exchanged with the boxes.
+    from .pageio import decode_pages
+    sizes, failures, decoded = [None] * n_pages, {}, {}
     for p, im in enumerate(images):
         try:
-            pages.append(Image.open(im).convert('RGB') if isinstance(im, str) else im.convert('RGB'))
+            if isinstance(im, str):
+                with Image.open(im) as f:
+                    sizes[p] = f.size
+            else:
+                sizes[p] = im.size
         except Exception as e:
-            pages.append(None)
             failures[p] = f'page {p}: cannot be read: {type(e).__name__}: {e}'
+
+    def need(idx):
+        """decode the pages of `idx` that are not decoded yet (thread pool); a failure becomes a marker"""
+        todo = [p for p in idx if p not in decoded and p not in failures]
+        for p, (page, arr, _) in zip(todo, decode_pages([images[p] for p in todo], eng.device)):
+            if page is None:
+                failures[p] = f'page {p}: cannot be read: {type(arr).__name__}: {arr}'
+            else:
+                decoded[p] = (page, arr)
+    need(range(rank, n_pages, world))
+    found = {}
     if boxes_list is None:
-        mine = {}
         for p in range(rank, n_pages, world):
-            if pages[p] is None:
+            if p in failures:
                 continue
             try:
-                mine[p] = [[int(v) for v in b[:4]] for b in ordering.acquire_boxes(detect_model, pages[p], model.sorter)]
+                found[p] = [[int(v) for v in b[:4]] for b in ordering.acquire_boxes(detect_model, decoded[p][0], model.sorter)]
             except Exception as e:
                 failures[p] = f'page {p}: detection failed on rank {rank}: {type(e).__name__}: {e}'
-        if world > 1:
-            got = [None] * world
-            dist.all_gather_object(got, (mine, failures), group=group)
-            mine = {k: v for g in got for k, v in g[0].items()}
-            failures = {k: v for g in got for k, v in g[1].items()}
-        boxes_list = [mine.get(p, []) for p in range(n_pages)]
+    if world > 1:                                        # boxes (when they were found here) and failure markers, in one exchange
+        got = [None] * world
+        dist.all_gather_object(got, (found, failures), group=group)
+        found = {k: v for g in got for k, v in g[0].items()}
+        failures = {k: v for g in got for k, v in g[1].items()}
     if failures:
         raise RuntimeError('chat_ocr_pages_sharded: ' + '; '.join(failures[p] for p in sorted(failures)))
+    if boxes_list is None:
+        boxes_list = [found.get(p, []) for p in range(n_pages)]
     if any(len(b) == 0 for b in boxes_list):
         raise RuntimeError('chat_ocr_pages_sharded: a page without character boxes (chat_ocr fails on it too: modeling_internvl_chat.py:585)')
     # ---- prompts (host work, the same on every rank): their lengths are the plan's prefill term ----
-    page_jobs = [plan_page(*pg.size) for pg in pages]                       # (jobs, tiles) per page
+    page_jobs = [plan_page(*sizes[p]) for p in range(n_pages)]              # (jobs, tiles) per page
     n_chars = [len(b) for b in boxes_list]
     template = get_conv_template(model.template)
     gen = dict(generation_config)
     gen['eos_token_id'] = tokenizer.convert_tokens_to_ids(template.sep)
     max_new, eos = model._gen_args(gen)
-    ids = []
-    for p in range(n_pages):
-        q = question if '<image>' in question else '<image>\n' + question
-        if ALIGNED_TOKEN not in q:
-            q = q + ALIGNED_TOKEN * (3 * n_chars[p])
-        query, _, _ = model._build_query(q, None, [page_jobs[p][1]], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN)
-        ids.append(tokenizer(query, return_tensors='pt')['input_ids'].reshape(-1))
+    q = question if '<image>' in question else '<image>\n' + question
+    ids = [model._prompt_ids(tokenizer, q, page_jobs[p][1], 3 * n_chars[p], IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN) for p in range(n_pages)]
     if plan is None:
         plan = plan_balanced(n_pages, world, [j[1] for j in page_jobs], n_chars, [int(i.numel()) for i in ids], max_new, cost=_resolve_cost(model, cost, group))
     off = plan['char_offsets']
     if len(plan['char_counts']) != world or off[-1] != sum(n_chars):
         raise ValueError('the plan was made for another world size or another batch')
-    # ---- my shard of the flat character-box list ----
+    # ---- my shard of the flat character-box list; the pixels of the pages it touches and of the pages I own: decoded now, on threads ----
     lo, hi = plan['char_bounds'][rank]
-    parts = []
-    for p in range(n_pages):
+    mine = plan['pages'][rank]
+    touched = [p for p in range(n_pages) if max(lo, off[p]) < min(hi, off[p + 1])]
+    need(sorted(set(touched) | set(mine)))
+    if failures:                                         # (every page was decoded once where it lives: this only fires if a file changed under us)
+        raise RuntimeError('chat_ocr_pages_sharded: ' + '; '.join(failures[p] for p in sorted(failures)))
+    dev_px = {p: decoded[p][1].to(eng.device, non_blocking=True) for p in sorted(set(touched) | set(mine))}
+    tot = hi - lo
+    char_px = torch.empty(tot, 3, eng.dims.image_size, eng.dims.image_size, device=eng.device, dtype=torch.bfloat16) if tot else None
+    o = 0
+    for p in touched:
         a, b = max(lo, off[p]), min(hi, off[p + 1])
-        if a >= b:
-            continue
-        w, h = pages[p].size
-        jobs = [plan_char((max(bx[0], 0), max(bx[1], 0), min(bx[2], w), min(bx[3], h)), j) for j, bx in enumerate(boxes_list[p][a - off[p]:b - off[p]])]
-        parts.append(eng.preprocess(torch.from_numpy(np.array(pages[p])), jobs, len(jobs)))
-    if parts:
-        pseudo, _ = model.align_tiles(torch.cat(parts), drop_zero=False, use_hard_vector_quant=hard_vq)
+        w, h = sizes[p]
+        eng.preprocess(dev_px[p], plan_chars_array(boxes_list[p][a - off[p]:b - off[p]], w, h, tile0=o), tot, out=char_px)
+        o += b - a
+    if tot:
+        pseudo, _ = model.align_tiles(char_px, drop_zero=False, use_hard_vector_quant=hard_vq)
         pseudo = pseudo.reshape(-1, 3, hidden)
     else:
         pseudo = torch.empty((0, 3, hidden), dtype=torch.bfloat16, device=eng.device)
     finish = all_gather_rows_async(pseudo, off[-1], group, counts=plan['char_counts'])
-    # ---- the pages I own: their tiles under the gather, splice, prefill + decode ----
-    mine = plan['pages'][rank]
-    feats = {p: model.extract_feature(eng.preprocess(torch.from_numpy(np.array(pages[p])), page_jobs[p][0], page_jobs[p][1])) for p in mine}
+    # ---- the pages I own: their tiles (ONE visual call) under the gather, splice, prefill + decode ----
+    feats = {}
+    if mine:
+        n_own = sum(page_jobs[p][1] for p in mine)
+        own_px = torch.empty(n_own, 3, eng.dims.image_size, eng.dims.image_size, device=eng.device, dtype=torch.bfloat16)
+        o = 0
+        for p in mine:
+            eng.preprocess(dev_px[p], jobs_array(plan_page(*sizes[p], tile0=o)[0]), n_own, out=own_px)
+            o += page_jobs[p][1]
+        f_all, o = model.extract_feature(own_px), 0
+        for p in mine:
+            feats[p] = f_all[o:o + page_jobs[p][1]]
+            o += page_jobs[p][1]
     pseudo_all = finish()
     embeds = [eng.embed_splice(ids[p], feats[p], pseudo_all[off[p]:off[p + 1]], img_id=model.img_context_token_id, ref_id=model.aligned_token_id) for p in mine]
     outs = model.generate_pages(embeds, max_new, eos, repetition_penalty) if embeds else []

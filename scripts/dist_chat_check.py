@@ -57,9 +57,39 @@ tiles = [plan_page(*im.size)[1] for im in images]
 toks = [60 + 256 * t + 3 * c for t, c in zip(tiles, n_chars)]           # (only the plan's cost estimate reads these)
 for pl in (plan_balanced(3, world, tiles, n_chars, toks, 5, owners=1), plan_even(3, world, tiles, n_chars, toks, 5)):
     outs.append(chat_ocr_pages_sharded(m, tok, det, images, q, gen, repetition_penalty=1.0, plan=pl))
+# round 6: the pages as FILES (sizes from the headers, pixels decoded on threads only where a rank needs them), boxes handed in, the plan under measured stage costs
+import tempfile
+tmp = tempfile.mkdtemp(prefix=f'cr_dist_chat_{rank}_')
+paths = []
+for k, im in enumerate(images):
+    paths.append(os.path.join(tmp, f'p{k}.png'))
+    im.save(paths[-1])
+from callireader_amd import ordering
+boxes = [[[int(v) for v in b[:4]] for b in ordering.acquire_boxes(det, im, m.sorter)] for im in images]
+outs.append(chat_ocr_pages_sharded(m, tok, None, paths, q, gen, boxes_list=boxes, repetition_penalty=1.0, cost='measure'))
+
+
+# a page nobody can read, and a detector that fails on ONE rank's page: every rank raises the same RuntimeError after the exchange (nobody waits in a collective)
+class FailsOnWide(Detector):
+    def __call__(self, arr, verbose=False):
+        if arr.shape[1] > 700:
+            raise ValueError('detector down')
+        return super().__call__(arr, verbose)
+
+
+errs = []
+for args, kw in (((None, paths + [os.path.join(tmp, 'missing.png')]), dict(boxes_list=boxes + [boxes[0]])), ((FailsOnWide(), images), {})):
+    try:
+        chat_ocr_pages_sharded(m, tok, args[0], args[1], q, gen, repetition_penalty=1.0, **kw)
+        errs.append(None)
+    except RuntimeError as e:
+        errs.append(str(e))
+all_errs = [None] * world
+dist.all_gather_object(all_errs, errs)
+same_errors = all(e == all_errs[0] for e in all_errs) and all(x is not None for x in errs) and 'cannot be read' in errs[0] and 'detection failed' in errs[1]
 if rank == 0:
     single = m.chat_ocr_pages(tok, det, images, q, gen, repetition_penalty=1.0)
-    ok = all(o == single for o in outs)
+    ok = all(o == single for o in outs) and same_errors
     print('DIST_CHAT', 'OK' if ok else 'MISMATCH', outs, single, flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -216,6 +216,11 @@ def test_chat_ocr_pages_equals_per_page_calls(setup):
     # the same pages as a stream of batches, two batches in flight (decode of one beside the visual stage of the next)
     streamed = list(m.chat_ocr_stream(tok, det, [[img], [img2, img], [img2]], '读出图中所有文字。', gen, repetition_penalty=1.0))
     assert streamed == [[singles[0]], [singles[1], singles[0]], [singles[1]]]
+    # the feeder's context BORROWS the sorter's weights: a switch on the owner (here the fp8 decode option, on and off again) invalidates what it holds, and the next
+    # batch must share again instead of failing with "the owner changed its weights"
+    m.engine.enable_fp8_decode(True)
+    m.engine.enable_fp8_decode(False)
+    assert m.chat_ocr_pages(tok, det, [img, img2], '读出图中所有文字。', gen, repetition_penalty=1.0) == singles
 
 
 def _write_folder(setup, d, n_good=5):
