@@ -277,7 +277,10 @@ def test_chat_ocr_stream_from_files_equals_chat_ocr_and_a_bad_page_fails_alone(s
     out = list(m.chat_ocr_stream(tok, None, [[good3[0]], [bad, good3[1]], [good3[2]]], q, gen, boxes_batches=[[boxes[0]], [None, []], [boxes[2]]],
                                  repetition_penalty=1.0, errors='return'))
     assert out[0] == [res[0]] and out[2] == [res[2]] and isinstance(out[1][0], FileNotFoundError) and isinstance(out[1][1], RuntimeError)
-    # drop_zero / hard_vq go through the same batch path
+    # without pseudo tokens (use_p=False: page tiles only, no detector needed) ...
+    b = m.chat_ocr_pages(tok, None, good3[:2], q, gen, use_p=False, repetition_penalty=1.0)
+    assert b == [m.chat_ocr(tok, None, p, q, gen, use_p=False, repetition_penalty=1.0) for p in good3[:2]]
+    # ... and drop_zero / hard_vq go through the same batch path
     a = m.chat_ocr_pages(tok, det, good3[:2], q, gen, repetition_penalty=1.0, drop_zero=True, hard_vq=True)
     assert a == [m.chat_ocr(tok, det, p, q, gen, repetition_penalty=1.0, drop_zero=True, hard_vq=True) for p in good3[:2]]
 
