@@ -151,6 +151,7 @@ def main(argv=None):
     parser.add_argument('--model', type=str, default='InternVL', help='checkpoint dir (INTERNVL_PATH)')
     parser.add_argument('--params', type=str, default='./params')
     parser.add_argument('--boxes', type=str, default=None, help='labelme-style JSON with ordered character boxes')
+    parser.add_argument('--max_new_tokens', type=int, default=1024, help='generation_config.max_new_tokens (inference.py:92-96: 1024)')
     parser.add_argument('--batch_pages', type=int, default=DEFAULT_BATCH_PAGES,
                         help='folder mode: pages per batch through chat_ocr_stream (two batches in flight; same responses as the serial loop, which 1 selects)')
     parser.add_argument('--fp8_decode', action='store_true', help='e4m3 weights for the decode (cr_enable_fp8_decode; off by default: the reference computes in bf16)')
@@ -170,7 +171,12 @@ def main(argv=None):
     # the engine's own reader of tokenizer.model (+ tokenizer_config.json / added_tokens.json): the reference's
     # AutoTokenizer path needs sentencepiece==0.2.0; any HF-style tokenizer object works with chat_ocr as well
     tokenizer = InternLM2Tokenizer.from_pretrained(args.model)
-    generation_config = dict(num_beams=1, max_new_tokens=1024, do_sample=False)
+    # the reference hard-codes the pseudo-token placeholder's id (92537, modeling_internvl_chat.py:1100); read from the tokenizer it is the same number on the
+    # reference's files and the right one on any other vocabulary
+    tid = tokenizer.convert_tokens_to_ids('[UNUSED_TOKEN_140]')
+    if isinstance(tid, int) and 0 < tid < model.dims.vocab and tid != tokenizer.sp_model.unk_id:
+        model.aligned_token_id = tid
+    generation_config = dict(num_beams=1, max_new_tokens=args.max_new_tokens, do_sample=False)
     detect_model = load_detector(args.params)
     if is_image(args.tgt):
         print('Single image recognition mode.')

@@ -315,6 +315,31 @@ def test_folder_rec_batched_gives_the_serial_loops_json(setup, tmp_path, capsys)
     assert batched == serial and [r['response'] for r in batched].count('ERROR!') == 2
 
 
+def test_inference_cli_folder_mode_on_a_checkpoint_from_disk(ckpt, tmp_path, monkeypatch, capsys):
+    """`python inference.py --tgt <folder> --model <checkpoint dir> --params <params dir>` end to end (callireader_amd.inference.main, the root inference.py's body): checkpoint,
+    tokenizer files and params from disk, no detector in this image (boxes from the JSON next to each image), batched folder mode against --batch_pages 1: the same results JSON."""
+    from callireader_amd import inference as inf
+    d = str(tmp_path / 'pages')
+    paths, bad = _write_folder(None, d, n_good=4)
+    raw = [[300, 310, 380, 480], [10, 20, 110, 140], [200, 50, 420, 300]]
+    for p in paths:
+        if p == bad:
+            continue
+        w, h = Image.open(p).size
+        shapes = [{'points': [[b[0] / w * 0.5, b[1] / h * 0.5], [b[2] / w * 0.5, b[3] / h * 0.5]]} for b in raw]
+        json.dump({'imageHeight': h, 'imageWidth': w, 'shapes': shapes}, open(os.path.splitext(p)[0] + '.json', 'w'))
+    monkeypatch.chdir(tmp_path)
+    common = ['--tgt', d, '--model', ckpt['dir'], '--params', ckpt['params'], '--max_new_tokens', '6']
+    inf.main(common + ['--save_name', 'batched.json', '--batch_pages', '3'])
+    inf.main(common + ['--save_name', 'serial.json', '--batch_pages', '1'])
+    a = json.load(open(tmp_path / 'results' / 'batched.json', encoding='utf-8'))
+    b = json.load(open(tmp_path / 'results' / 'serial.json', encoding='utf-8'))
+    assert a == b and [r['imagePath'] for r in a] == paths
+    assert [r['response'] == 'ERROR!' for r in a] == [p == bad for p in paths]              # the truncated JPEG (it has no boxes JSON either) and nothing else
+    assert all(r['prompt'] == '这幅书法作品内容是什么？' for r in a)
+    assert 'Multiple images recognition mode' in capsys.readouterr().out
+
+
 def test_dynamic_chat_and_generate(setup):
     m, tok, img = setup['model'], setup['tok'], setup['img']
     px = preprocess.load_image(img).to(torch.bfloat16).cuda()
