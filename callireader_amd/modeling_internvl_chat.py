@@ -511,11 +511,19 @@ class InternVLChatModel:
             while ahead:
                 cur = ahead.popleft()
                 tile(cur)
-                if isinstance(cur[3], Exception):
-                    raise cur[3]
-                embeds, meta = self._ocr_embeds(tokenizer, None, cur[0], question, generation_config, None, use_p, drop_zero, hard_vq,
-                                                IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, tiles=cur[3], errors=errors,
-                                                mark=marks if stats is not None else None)
+                try:
+                    if isinstance(cur[3], Exception):
+                        raise cur[3]
+                    embeds, meta = self._ocr_embeds(tokenizer, None, cur[0], question, generation_config, None, use_p, drop_zero, hard_vq,
+                                                    IMG_START_TOKEN, IMG_END_TOKEN, IMG_CONTEXT_TOKEN, ALIGNED_TOKEN, tiles=cur[3], errors=errors,
+                                                    mark=marks if stats is not None else None)
+                except Exception:
+                    # this batch fails as a whole (errors='raise', or the visual stage itself): the batch before it is still decoding and its responses are good --
+                    # they are handed out first, then the failure surfaces (folder mode re-runs exactly the failing batch page by page)
+                    if pending is not None:
+                        done, pending = pending, None
+                        yield self._responses(tokenizer, pipe.finish(), done)
+                    raise
                 # batch i+1's tiles BEFORE this thread blocks for batch i-1's decode: when it comes back the compute stream is close to the end of batch i's
                 # prefill, and the first kernel of batch i+1 must not wait for 64 uploads to be issued (measured: 40-60 ms of idle compute stream per batch)
                 if ahead:

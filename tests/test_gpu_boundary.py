@@ -267,6 +267,12 @@ def test_chat_ocr_stream_from_files_equals_chat_ocr_and_a_bad_page_fails_alone(s
     # errors='raise' (the default) keeps chat_ocr's behaviour for the batch
     with pytest.raises(FileNotFoundError):
         m.chat_ocr_pages(tok, det, paths, q, gen, repetition_penalty=1.0)
+    # ... and in a stream the batches BEFORE the failing one are still handed out: their decode was in flight and their responses are good
+    seen = []
+    with pytest.raises(FileNotFoundError):
+        for res in m.chat_ocr_stream(tok, det, [paths[:2], [paths[2]], [bad], [paths[5]]], q, gen, repetition_penalty=1.0):
+            seen.append(res)
+    assert seen == [[want[p] for p in paths[:2]], [want[paths[2]]]]
     # boxes handed in per page; a page with an empty list fails alone with the reference's RuntimeError, a batch of failures only yields in order
     boxes = [[list(b) for b in setup['raw'][:3]], [], [list(b) for b in setup['raw'][:2]]]
     good3 = [p for p in paths if p != bad][:3]
