@@ -110,6 +110,17 @@ class InternVLChatModel:
     def cuda(self):
         return self
 
+    def close(self):
+        """Release what the model holds on the device and the host: the page feeder (its decode threads, stream and context), the KV cache, the engine's context."""
+        f = getattr(self, '_pagefeeder', None)
+        if f is not None:
+            f.close()
+            self._pagefeeder = None
+        if self._kv is not None:
+            self._kv.free()
+            self._kv = None
+        self.engine.close()
+
     def kv(self):
         if self._kv is None:
             self._kv = self.engine.kv_alloc(self.max_pages, self.max_tokens)
