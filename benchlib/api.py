@@ -64,6 +64,57 @@ def make_pages(d, n, root):
     return paths, boxes
 
 
+class _Box:
+    def __init__(self, b):
+        self.xyxy = torch.tensor([b], dtype=torch.float32)
+
+
+class _Result:
+    def __init__(self, boxes):
+        self.boxes = [_Box(b) for b in boxes]
+
+
+class _DetectorStandIn:
+    """ultralytics.YOLO's call shape; the boxes of the example page in an order that is not the reading order."""
+
+    def __init__(self, boxes):
+        self.boxes = [list(b) for b in boxes]
+        random.Random(1).shuffle(self.boxes)
+        self.result = [_Result(self.boxes)]
+
+    def __call__(self, image, verbose=True):
+        return self.result
+
+
+def _with_detector(model, tok, batch_paths, boxes, gen, pages):
+    from callireader_amd import synthetic
+    had = model.sorter
+    if had is None:
+        model.load_orderformer(synthetic.make_orderformer_state_dict(seed=11))
+    det = _DetectorStandIn(boxes)
+    try:
+        list(model.chat_ocr_stream(tok, det, batch_paths[:1], PROMPT, gen, repetition_penalty=1.0))          # warm-up (the sorter's first launches)
+        stats = {}
+        t0 = time.perf_counter()
+        ts, n = [], 0
+        for res in model.chat_ocr_stream(tok, det, batch_paths, PROMPT, gen, repetition_penalty=1.0, stats=stats):
+            ts.append(time.perf_counter())
+            n += len(res)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    finally:
+        if had is None:
+            model.sorter = None
+    gaps = sorted(b - a for a, b in zip(ts, ts[1:]))
+    host = stats.get('host', {})
+    return {'what': 'chat_ocr_stream(tokenizer, detect_model, batches of file paths, prompt, gen): a detector OBJECT with the ultralytics call shape (a stand-in that returns the example page\'s 96 boxes '
+                    'shuffled; the YOLO network is third-party) and everything behind it per page: de-duplication, columns, OrderFormer on the GPU (seeded weights), reading order',
+            'pages': n, 'batches': len(batch_paths), 'wall_s': round(wall, 3), 'pages_per_s': round(n / wall, 4),
+            'steady_ms_per_batch': round(gaps[len(gaps) // 2] * 1e3, 1) if gaps else None,
+            'ordering_front_end_ms_per_page': round(1e3 * host.get('detect_s', 0.0) / max(host.get('pages', 1), 1), 3),
+            'compute_stream_idle_ms_between_batches': stats.get('compute_stream_idle_ms_between_batches')}
+
+
 def api_level(model, root, pages=64, batches=4, new_tokens=128, folder_pages=128, headline_ms_per_step=None, headline_pages=None):
     from callireader_amd import inference as inf
     from callireader_amd.tokenization_internlm2 import InternLM2Tokenizer
@@ -121,6 +172,14 @@ def api_level(model, root, pages=64, batches=4, new_tokens=128, folder_pages=128
             model.chat_ocr(tok, None, paths[1 + k], PROMPT, gen, boxes=boxes, repetition_penalty=1.0)
         torch.cuda.synchronize()
         res['chat_ocr_single_page_s'] = round((time.perf_counter() - t0) / 3, 4)
+        # ---- the reference's call shape WITH a detector object: detect_model(image array, verbose=False)[0].boxes[i].xyxy (inference.py:98, modeling_internvl_chat.py:356-362) ----
+        # The YOLO network itself is third-party and not in this image: the stand-in returns the example's 96 boxes in a shuffled order, and everything behind the detector
+        # runs as for real pages -- duplicate removal, column merge / 2-means split, the OrderFormer on the GPU (seeded weights), per-column assembly (ordering.py) -- on the
+        # feeder's stream and context, page by page, before the tiles are cut.
+        try:
+            res['with_detector_object'] = _with_detector(model, tok, batch_paths[:min(3, len(batch_paths))], boxes, gen, pages)
+        except Exception as e:
+            res['with_detector_object'] = {'error': f'{type(e).__name__}: {e}'}
         # ---- the reference's folder mode (inference.py:47-62) on the batched path ----
         fpaths, _ = make_pages(folder_dir, folder_pages, root)
         save = os.path.join(work, 'recognition.json')

@@ -4,6 +4,7 @@ scorer; and the oracle model against the reference's scores."""
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -78,3 +79,60 @@ def test_too_many_columns_is_an_error(scorer):
     page = {'imageWidth': 100, 'imageHeight': 100, 'shapes': [{'points': [[i, 0], [i + 1, 5]]} for i in range(51)]}
     with pytest.raises(ValueError):
         ordering.OrderFormer(scorer, max_nums=50).predict(page)
+
+
+def test_clean_detections_fast_path_is_the_sweep_and_the_dominant_colour_keeps_its_tie_rule():
+    """Round 6 (host time per page on the thread that feeds the GPU): clean_detections answers from one vectorised IoU matrix when no pair exceeds the threshold and runs the
+    reference's sweep (:369-392, removal by value) otherwise -- against the sweep alone on 400 random box sets, a third of them with near-duplicates; most_frequent_rgb by
+    np.unique keeps bincount + argmax's tie rule (the smallest packed colour) and detect_all only computes it when a pass returns more than 250 boxes."""
+    import random
+    from callireader_amd import ordering
+
+    def sweep(boxes, width, height, thr=0.8):
+        out = [[[max(b[0], 0), max(b[1], 0)], [min(b[2], width), min(b[3], height)]] for b in boxes]
+        i, n = 0, len(out)
+        while i < n:
+            keep, j = out[i], 0
+            while j < n:
+                if j != i and ordering.box_iou(ordering._flat(keep), ordering._flat(out[j])) > thr:
+                    out.remove(out[j])
+                    if j < i:
+                        i -= 1
+                    n -= 1
+                    j -= 1
+                j += 1
+            i += 1
+        return out
+    rng = random.Random(3)
+    for t in range(400):
+        bs = []
+        for _ in range(rng.randint(1, 60)):
+            x1, y1 = rng.randint(-5, 700), rng.randint(-5, 1900)
+            bs.append([x1, y1, x1 + rng.randint(5, 120), y1 + rng.randint(5, 120)])
+        if t % 3 == 0:
+            for _ in range(rng.randint(1, 5)):
+                b = rng.choice(bs)
+                bs.append([b[0] + rng.randint(0, 3), b[1] + rng.randint(0, 3), b[2] + rng.randint(0, 3), b[3]])
+        assert ordering.clean_detections(bs, 788, 2000) == sweep(bs, 788, 2000), t
+    g = np.random.default_rng(0)
+    for _ in range(8):
+        a = (g.integers(0, 4, (40, 50, 3)) * 60).astype(np.uint8)
+        flat = a.reshape(-1, 3).astype(np.int64)
+        top = int(np.argmax(np.bincount((flat[:, 0] << 16) | (flat[:, 1] << 8) | flat[:, 2])))
+        assert ordering.most_frequent_rgb(a) == ((top >> 16) & 255, (top >> 8) & 255, top & 255)
+    calls = []
+    orig = ordering.most_frequent_rgb
+    ordering.most_frequent_rgb = lambda im: calls.append(1) or orig(im)
+    try:
+        page = np.full((300, 300, 3), 200, dtype=np.uint8)
+        few = [[10 * k, 10, 10 * k + 8, 40] for k in range(20)]
+        assert ordering.detect_all(lambda arr, verbose=False: few, page) == few and not calls
+        many = [[(k % 28) * 10, (k // 28) * 10, (k % 28) * 10 + 8, (k // 28) * 10 + 8] for k in range(260)]
+        state = {'n': 0}
+
+        def det(arr, verbose=False):
+            state['n'] += 1
+            return many if state['n'] == 1 else few
+        assert ordering.detect_all(det, page) == many + few and len(calls) == 1
+    finally:
+        ordering.most_frequent_rgb = orig
