@@ -24,7 +24,7 @@ from PIL import Image
 from .config import ModelDims, IMG_CONTEXT_TOKEN_ID, ALIGNED_TOKEN_ID, EOS_TOKEN_ID
 from .conversation import get_conv_template
 from .engine import Engine
-from .preprocess import load_image, load_image_2, plan_page, plan_char
+from .preprocess import load_image, load_image_2, plan_page, plan_chars_array
 
 
 class InternVLChatModel:
@@ -192,11 +192,7 @@ class InternVLChatModel:
         if self.gpu_preprocess:
             # one page upload, every crop resized/padded/normalised by cr_preprocess (replaces the per-box PIL loop :580-583)
             h, w = arr.shape[:2]
-            jobs = []
-            for i, xyxy in enumerate(boxes):
-                x1, y1, x2, y2 = [int(v) for v in xyxy[:4]]
-                x1, y1, x2, y2 = max(x1, 0), max(y1, 0), min(x2, w), min(y2, h)        # numpy slicing clips the same way
-                jobs.append(plan_char((x1, y1, x2, y2), i))
+            jobs = plan_chars_array(boxes, w, h)                                          # clipped to the page, as numpy slicing clips the reference's crops
             results = self.engine.preprocess(torch.from_numpy(arr), jobs, len(jobs))
         else:
             tiles = []
