@@ -121,9 +121,11 @@ class InternVLChatModel:
             self._kv = None
         self.engine.close()
 
-    def kv(self):
+    def kv(self, n_seqs=None):
+        """The model's own KV cache (the pipeline of chat_ocr_stream has two of its own): `n_seqs` sequences when none exists yet (default: max_pages).  The one-page
+        calls ask for ONE sequence -- 1 GB at max_tokens 8192, where a 64-page cache is 69 GB that folder mode's per-image fallback would hold beside the pipeline's."""
         if self._kv is None:
-            self._kv = self.engine.kv_alloc(self.max_pages, self.max_tokens)
+            self._kv = self.engine.kv_alloc(n_seqs or self.max_pages, self.max_tokens)
         return self._kv
 
     # ---- the * stages --------------------------------------------------------------------------
@@ -212,7 +214,7 @@ class InternVLChatModel:
     def _greedy(self, input_embeds, max_new_tokens, eos_token_id, repetition_penalty, check_every=16):
         """transformers 4.45.2 GenerationMixin._sample with do_sample=False, num_beams=1, for ONE sequence:
         returns only the new ids, EOS included (oracle/generate.py documents the semantics)."""
-        kv = self.kv()
+        kv = self.kv(1)
         kv.reset(0)
         if input_embeds.shape[0] + max_new_tokens > self.max_tokens:
             raise ValueError(f'prompt of {input_embeds.shape[0]} tokens + {max_new_tokens} new exceeds max_tokens={self.max_tokens}')
