@@ -52,6 +52,35 @@ def by_kernel(dev, vit_tiles=255, prefill_pages=16, prompt=3164, decode_rows=64,
     gemm('llm_w2', 'InternLM2 w2 + residual', EPI_RES, Mp, 4096, 14336, res=True)
     gemm('resampler_to_kv', 'PerceiverResampler to_kv, 252-tile chunk', EPI_STORE, 252 * 259, 1024, 4096)
 
+    # the weight streams of a 64-row decode step (HBM-bound): the K-sliced partial-sum GEMMs for wqkv / wo / w2 and the X-through-LDS stream kernel for w1|w3, each on the
+    # decode-layout copy of its weight as the product keeps it, alternating between three weight copies so that nothing is served from L2 / the Infinity Cache
+    def stream(name, what, epi, which, N, K, M=decode_rows):
+        A = rnd(M, K)
+        Ws = [rnd(N, K, scale=0.05) for _ in range(3)]
+        kind = 2 if (which == 0 and epi == 7) else 1
+        SW = [E.op_decode_swizzle(which if (kind == 2 or which) else 1, W) for W in Ws]
+        C = E.op_gemm(epi, A, Ws[0])
+        state = {'i': 0}
+
+        def f():
+            i = state['i'] = (state['i'] + 1) % 3
+            E.op_gemm(epi, A, Ws[i], out=C, decode_layout=(kind, SW[i]))
+        ms = _timed(f, reps=30)
+        gbs = N * K * 2 / (ms * 1e-3) / 1e9
+        out[name] = {'what': what, 'shape_MNK': [M, N, K], 'ms': round(ms, 4), 'bound': 'hbm', 'achieved': round(gbs, 1), 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                     'bytes': N * K * 2, 'note': 'weight bytes only (the activations add M x K x 2 per workgroup column through L2)'}
+    stream('decode_wqkv', f'InternLM2 wqkv at {decode_rows} decode rows (gemm_skinny_kernel, K-sliced fp32 partial sums)', 7, 0, 6144, 4096)
+    stream('decode_wo', 'InternLM2 wo (K-sliced partial sums)', 7, 1, 4096, 4096)
+    stream('decode_w1w3_swiglu', 'InternLM2 w1|w3 + SwiGLU (gemm_stream_kernel: X through LDS)', EPI_SWIGLU, 2, 28672, 4096)
+    stream('decode_w2', 'InternLM2 w2 (K-sliced partial sums)', 7, 3, 4096, 14336)
+    # LayerNorm of the ViT (HBM-bound: one read, one write)
+    x = rnd(Mv, 1024)
+    gam, bet = rnd(1024), rnd(1024)
+    ms = _timed(lambda: E.op_layernorm(x, gam, bet, 1e-6))
+    gbs = 2.0 * Mv * 1024 * 2 / (ms * 1e-3) / 1e9
+    out['vit_layernorm'] = {'what': f'InternViT LayerNorm, {vit_tiles}-tile chunk', 'ms': round(ms, 4), 'bound': 'hbm', 'achieved': round(gbs, 1), 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4)}
+    del x
+
     # ViT attention (16 heads x 64, 1025 tokens, no mask): modeling_intern_vit.py:215-232
     S, H, D = 1025, 16, 64
     qkv = rnd(vit_tiles, S, 3 * H * D)
@@ -62,7 +91,7 @@ def by_kernel(dev, vit_tiles=255, prefill_pages=16, prompt=3164, decode_rows=64,
     tf = 4.0 * S * S * D * H * vit_tiles / (ms * 1e-3) / 1e12
     out['vit_attn'] = {'what': f'InternViT attention, {vit_tiles} tiles x 16 heads x 1025 x 64 (vit_attn_kernel)', 'ms': round(ms, 4), 'bound': 'mfma', 'achieved': round(tf, 1), 'unit': 'TFLOP/s',
                        'frac': round(tf / PEAK_BF16_TFLOPS, 4),
-                       'note': 'vector-issue bound, not LDS bound (profiles/round6: LDS array 21 % busy, 0 bank conflicts; 45 issue cycles of softmax VALU per 32-cycle MFMA)'}
+                       'note': 'vector-issue bound, not LDS bound (profiles/round6: LDS array 24 % busy, 0 bank-conflict cycles; 45 issue cycles of softmax VALU per 32-cycle MFMA)'}
     del qkv, o
     # LLM causal prefill attention (32 query / 8 KV heads x 128): modeling_internlm2.py:390-410; the pages of a prefill batch as the batch dimension
     NH, NKV, HD, Bp = 32, 8, 128, prefill_pages
