@@ -177,7 +177,7 @@ def api_level(model, root, pages=64, batches=4, new_tokens=128, folder_pages=128
         # runs as for real pages -- duplicate removal, column merge / 2-means split, the OrderFormer on the GPU (seeded weights), per-column assembly (ordering.py) -- on the
         # feeder's stream and context, page by page, before the tiles are cut.
         try:
-            res['with_detector_object'] = _with_detector(model, tok, batch_paths[:min(3, len(batch_paths))], boxes, gen, pages)
+            res['with_detector_object'] = _with_detector(model, tok, batch_paths[:min(2, len(batch_paths))], boxes, gen, pages)
         except Exception as e:
             res['with_detector_object'] = {'error': f'{type(e).__name__}: {e}'}
         # ---- the reference's folder mode (inference.py:47-62) on the batched path ----
